@@ -1,0 +1,199 @@
+"""bench.py -- images/sec of one MUNIT training step (dis_update + gen_update) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--batch 8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic batch: MUNIT_Trainer.update_learning_rate,
+dis_update, gen_update (each consumes `batch` images of each domain, runs forward, backward, the
+data-parallel gradient all-reduce when N > 1, and the Adam step).  Workload at N = 1 is BASELINE.json
+configs[1]: config_256.yaml geometry (AdaINGen_double + MsImageDis, gen_state 1, guided 1,
+recon_mask 1, aux losses 0), 256x256, batch 8, fp32.  N > 1 is weak scaling: every rank runs the same
+per-GPU batch on its own shard of the global batch (data seed 7 + rank, identical model seed).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (forward implicit-GEMM conv on v_mfma_f32_32x32x2_f32) measured
+                  with HIP events around its launches in extra instrumented steps of this same run
+  cpu_baseline -- the CPU oracle (oracle/munit_oracle.py, a torch-CPU restatement of the
+                  reference step: kind "port") timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+GFLOP_PER_PAIR_256 = 2789.6   # algorithmic conv+linear FLOPs of dis_update+gen_update
+
+
+def bench_hp(size, batch, gen_state=1):
+    """configs/config_256.yaml with the overrides of SURVEY.md section 8(d)."""
+    return dict(
+        batch_size=batch, weight_decay=1e-4, beta1=0.5, beta2=0.999, init="kaiming", lr=1e-4,
+        lr_policy="step", step_size=100000, gamma=0.5, gan_w=3, recon_x_w=12, recon_s_w=1, recon_c_w=2,
+        recon_x_cyc_w=12, vgg_w=0,
+        adaptation=dict(full_adaptation=0, output_classifier_lambda=0, output_adv_lambda=0, output_classif_freq=1,
+                        adv_lambda=0, dfeat_lambda=0, classif_frequency=15, sem_seg_lambda=0),
+        semantic_w=0, recon_mask=1, domain_adv_w=0, recon_synth_w=0, gen_state=gen_state, guided=1,
+        gen=dict(dim=64, mlp_dim=256, style_dim=16, activ="relu", n_downsample=2, n_res=4, pad_type="reflect"),
+        dis=dict(dim=64, norm="none", activ="lrelu", n_layer=4, gan_type="lsgan", num_scales=3, pad_type="reflect"),
+        ratio_disc_gen=5, input_dim_a=3, input_dim_b=3, display_size=8, optimizer="adam",
+        crop_image_height=size, crop_image_width=size, new_size=size, num_workers=0)
+
+
+def make_batch(batch, size, rank=0):
+    """Synthetic two-domain batch: x = 2U - 1, mask = (U > 0.5); seed 7 + rank."""
+    g = torch.Generator().manual_seed(7 + rank)
+    x_a = 2 * torch.rand(batch, 3, size, size, generator=g) - 1
+    x_b = 2 * torch.rand(batch, 3, size, size, generator=g) - 1
+    m_a = (torch.rand(batch, 1, size, size, generator=g) > 0.5).float()
+    m_b = (torch.rand(batch, 1, size, size, generator=g) > 0.5).float()
+    return x_a, x_b, m_a, m_b
+
+
+def cpu_baseline(size, seconds_budget=30.0):
+    """The oracle's dis_update + gen_update on the host cores, batch 1 at the bench resolution."""
+    from oracle import munit_oracle as O
+    from tests.parity import oracle_states
+    hp = O.default_hp(size, 1, 1)
+    gen, dis_a, dis_b = oracle_states(hp, torch.float32)
+    orc = O.OracleTrainer(hp, gen, dis_a, dis_b)
+    x_a, x_b, m_a, m_b = O.synthetic_batch(1, size, seed=7)
+
+    def one():
+        orc.update_learning_rate()
+        orc.dis_update(x_a, x_b)
+        orc.gen_update(x_a, x_b, m_a, m_b)
+
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and el + el / n > seconds_budget or n >= 8:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/munit_oracle.py (torch %s CPU fp32), %dx%d batch 1, 1 warm-up + %d timed "
+                      "dis_update+gen_update steps" % (torch.__version__, size, size, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (pairs per update)")
+    ap.add_argument("--gen-state", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from munit_amd import _lib, ops
+    _lib.load()  # fail loudly before anything else if the HIP library is missing
+    from munit_amd.trainer import MUNIT_Trainer
+
+    hp = bench_hp(args.size, args.batch, args.gen_state)
+    torch.manual_seed(1234)
+    trainer = MUNIT_Trainer(hp)
+    trainer.to(dev)
+    x_a, x_b, m_a, m_b = (t.to(dev) for t in make_batch(args.batch, args.size, rank))
+
+    def step():
+        trainer.update_learning_rate()
+        trainer.dis_update(x_a, x_b, hp)
+        trainer.gen_update(x_a, x_b, hp, m_a, m_b)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_total = float(trainer.loss_gen_total)
+    assert loss_total == loss_total, "loss is NaN"
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = args.batch * world * args.steps / elapsed
+    out = {
+        "metric": "images/sec (gen_update+dis_update) @%dx%d bs=%d" % (args.size, args.size, args.batch),
+        "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config_256.yaml AdaINGen_double+MsImageDis dis_update+gen_update, %dx%d, "
+                               "per-GPU batch %d, fp32" % (args.size, args.size, args.batch),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "gen_state": args.gen_state, "loss_gen_total": round(loss_total, 5)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        step_flop = GFLOP_PER_PAIR_256 * 1e9 * (args.size / 256.0) ** 2 * args.batch
+        ops.PROFILE = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        sel = [(fl, e0.elapsed_time(e1)) for (tag, fl, e0, e1) in recs if tag == "conv_igemm_kernel<128,true,fwd>"]
+        if sel:
+            tot_fl = sum(f for f, _ in sel)
+            tot_ms = sum(t for _, t in sel)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "conv_igemm_kernel<128,true,fwd> (forward implicit-GEMM conv, Cout>64, Cin%32==0)",
+                "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
+                "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),
+                "method": "HIP events around every launch of the kernel in 2 extra instrumented steps after "
+                          "the timed region; algorithmic FLOPs = 2*B*Ho*Wo*Cout*KH*KW*Cin per launch",
+                "step_achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
+                "step_frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_algorithmic_tflop": round(step_flop / 1e12, 3),
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * munit_hip.h -- C ABI of libmunit_hip.so: the gfx950 (MI355X / CDNA4) kernels behind the
+ * MUNIT AdaINGen / AdaINGen_double + MsImageDis training step.
+ *
+ * The reference (cc-ai/MUNIT) is pure Python on PyTorch and has no FFI of its own
+ * (SURVEY.md section 0.1); every entry point below therefore replaces a *stock torch op
+ * call site* of the reference hot path, cited as scripts/<file>:<line>.  The Python side
+ * (munit_amd/ops.py) binds these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - All tensor pointers are DEVICE pointers to float32.  Activations are NHWC
+ *     ([B][H][W][C], C contiguous) -- the memory image of a torch channels_last tensor.
+ *     Convolution weights are [Cout][KH][KW][Cin] -- the memory image of a torch OIHW
+ *     tensor in channels_last format, so state_dict shapes stay (O, I, KH, KW).
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*); the library
+ *     never synchronises, allocates no device memory and keeps no state between calls.
+ *     The caller owns every buffer, including the workspace `ws` (size from the matching
+ *     *_workspace_bytes query; must be 256-byte aligned).
+ *   - Return value: 0 on success, negative on error; munit_last_error() returns a
+ *     thread-local description of the last failure.
+ */
+#ifndef MUNIT_HIP_H
+#define MUNIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* munit_stream_t; /* hipStream_t */
+
+enum { MUNIT_OK = 0, MUNIT_ERR_ARG = -1, MUNIT_ERR_WORKSPACE = -2, MUNIT_ERR_LAUNCH = -3 };
+enum { MUNIT_ACT_NONE = 0, MUNIT_ACT_RELU = 1, MUNIT_ACT_LRELU = 2, MUNIT_ACT_TANH = 3 };
+enum { MUNIT_PAD_ZERO = 0, MUNIT_PAD_REFLECT = 1 };
+
+int munit_version(void);
+const char* munit_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution.  Replaces nn.ReflectionPad2d/ZeroPad2d + nn.Conv2d (+ bias + activation)
+ * of Conv2dBlock.forward (scripts/networks.py:695-701, pads :642-649, conv :691-693),
+ * the bare nn.Conv2d heads (networks.py:68, :472), nn.Linear of LinearBlock
+ * (networks.py:712, as a 1x1 convolution on a [B][1][1][K] image) and, with
+ * upsample = 1, the nn.Upsample(scale_factor=2) + 5x5 conv pair of the decoder
+ * (networks.py:532-546) without materialising the upsampled tensor.
+ *   x: [B][H][W][Cin]   w: [Cout][KH][KW][Cin]   bias: [Cout] or NULL
+ *   y: [B][Ho][Wo][Cout],  Ho = ((H << upsample) + 2*pad - KH) / stride + 1
+ * act is applied after the bias (MUNIT_ACT_*; slope = LeakyReLU negative slope).
+ * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged NHWC tiles.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  int B, H, W, Cin;
+  int Cout, KH, KW;
+  int stride, pad, pad_mode; /* MUNIT_PAD_* */
+  int upsample;              /* 0 or 1: nearest x2 of x before padding */
+  int act;                   /* MUNIT_ACT_* fused after bias (fwd only) */
+  float slope;
+} munit_conv_desc;
+
+int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo);
+
+int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w, const float* bias,
+                     float* y, munit_stream_t stream);
+
+/* backward-data (autograd of the sites above): dx[B][H][W][Cin] from dy[B][Ho][Wo][Cout]
+ * (dy is the gradient w.r.t. the PRE-activation output; use munit_act_bwd first when an
+ * activation was fused).  Handles the adjoint of reflect padding (border fold-add) and of
+ * the nearest upsample (2x2 sum).  If add != NULL, dx = result + add (same shape). */
+size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d);
+int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w, const float* add,
+                       float* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
+
+/* backward-weight: dw = beta*dw + sum_m dy[m][co] * im2col(x)[m][kh][kw][ci], layout of w;
+ * db = beta*db + sum_m dy[m][co] when db != NULL.  Deterministic split-K (slabs in ws). */
+size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d);
+int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
+                       float* db, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
+
+/* dx = dy * act'(y) for the fused activations (y = post-activation output). n elements. */
+int munit_act_bwd(int act, float slope, const float* y, const float* dy, float* dx, size_t n,
+                  munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Instance norm / AdaIN.  Replaces nn.InstanceNorm2d(affine=False)
+ * (scripts/networks.py:657) and AdaptiveInstanceNorm2d.forward = F.batch_norm on the
+ * (1, B*C, H, W) view (networks.py:823-845): per-(b,c) mean and BIASED variance over HW,
+ *   y = act( (x - mean) * rsqrt(var + eps) * weight[b][c] + bias[b][c] ) + residual
+ * adain == NULL -> weight 1 / bias 0.  Otherwise weight[b][c] = adain[b*ad_ld + w_off + c],
+ * bias[b][c] = adain[b*ad_ld + b_off + c] (the slicing of assign_adain_params,
+ * networks.py:230-239, done by address).  relu: 0/1.  residual may be NULL
+ * (ResBlock's `out += residual`, networks.py:620-624).
+ * stats: [B][C][2] (mean, rstd) written for the backward.  C % 4 == 0.
+ * ------------------------------------------------------------------------------------ */
+size_t munit_instnorm_workspace_bytes(int B, int HW, int C);
+int munit_instnorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                       const float* adain, int ad_ld, int w_off, int b_off, const float* residual,
+                       int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream);
+/* dx from dy (gradient w.r.t. y before the residual add; the residual's gradient is dy
+ * itself).  d_adain (same addressing as adain) receives dweight/dbias when not NULL. */
+int munit_instnorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                       int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
+                       int relu, void* ws, size_t ws_bytes, munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * MUNIT's custom LayerNorm (scripts/networks.py:851-878): per-sample mean and UNBIASED
+ * std over C*H*W, y = act( (x - mean) / (std + eps) * gamma[c] + beta[c] ).
+ * stats: [B][2] (mean, std).  C % 4 == 0.
+ * ------------------------------------------------------------------------------------ */
+size_t munit_layernorm_workspace_bytes(int B, int HW, int C);
+int munit_layernorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                        const float* gamma, const float* beta, int relu, float eps, void* ws,
+                        size_t ws_bytes, munit_stream_t stream);
+/* dgamma/dbeta: = acc*old + new (acc 0 or 1). */
+int munit_layernorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                        int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                        float acc, int relu, float eps, void* ws, size_t ws_bytes,
+                        munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pooling.  nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)
+ * (scripts/networks.py:32-34) and nn.AdaptiveAvgPool2d(1) (networks.py:471).
+ * ------------------------------------------------------------------------------------ */
+int munit_avgpool3s2_fwd(const float* x, float* y, int B, int H, int W, int C, munit_stream_t stream);
+int munit_avgpool3s2_bwd(const float* dy, float* dx, int B, int H, int W, int C, munit_stream_t stream);
+int munit_gap_fwd(const float* x, float* y, int B, int HW, int C, munit_stream_t stream);
+int munit_gap_bwd(const float* dy, float* dx, int B, int HW, int C, munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Losses.  torch.mean(torch.abs(a - b)) (scripts/trainer.py:290), the masked form
+ * torch.mean(torch.abs((a - b) * (1 - mask))) (trainer.py:305; mask is [B][H][W], one value
+ * per pixel, broadcast over C) and LSGAN torch.mean((x - target)**2) (networks.py:91,109).
+ * out: one device float (written, deterministic two-stage reduction, partials in ws).
+ * Backward: gout is a DEVICE scalar (upstream gradient, already times the loss weight).
+ * ------------------------------------------------------------------------------------ */
+size_t munit_loss_workspace_bytes(size_t n);
+int munit_l1_mean_fwd(const float* a, const float* b, const float* mask, size_t npix, int C, float* out,
+                      void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_l1_mean_bwd(const float* a, const float* b, const float* mask, size_t npix, int C,
+                      const float* gout, float* da, float* db, munit_stream_t stream);
+int munit_mse_const_fwd(const float* x, float target, size_t n, float* out, void* ws, size_t ws_bytes,
+                        munit_stream_t stream);
+int munit_mse_const_bwd(const float* x, float target, size_t n, const float* gout, float* dx,
+                        munit_stream_t stream);
+/* out = sum_i w[i] * *(terms[i]); n <= 32; terms are device scalars, w host floats. */
+int munit_weighted_sum(const float* const* terms, const float* w, int n, float* out,
+                       munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam as configured at scripts/trainer.py:109-120: L2-coupled
+ * weight_decay, amsgrad off) over one flat fp32 buffer of n elements.  step >= 1.
+ * ------------------------------------------------------------------------------------ */
+int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, munit_stream_t stream);
+
+/* y[i] = alpha * x[i] (+ y[i] if accumulate); used for the 1/world gradient averaging. */
+int munit_scale(const float* x, float* y, size_t n, float alpha, int accumulate, munit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUNIT_HIP_H */

@@ -1,0 +1,58 @@
+// Shared host/device helpers for libmunit_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/munit_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void munit_set_error(const char* fmt, ...);
+
+#define MUNIT_CHECK_ARG(cond, ...)         \
+  do {                                     \
+    if (!(cond)) {                         \
+      munit_set_error(__VA_ARGS__);        \
+      return MUNIT_ERR_ARG;                \
+    }                                      \
+  } while (0)
+
+#define MUNIT_CHECK_LAUNCH(what)                                                   \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      munit_set_error("%s: launch failed: %s", what, hipGetErrorString(e_));       \
+      return MUNIT_ERR_LAUNCH;                                                     \
+    }                                                                              \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Wave64 sum (all lanes get the total).
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ inline float apply_act(float v, int act, float slope) {
+  if (act == MUNIT_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == MUNIT_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == MUNIT_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// Map a coordinate of the padded (and optionally x2-upsampled) domain back to the source.
+// v is in upsampled-domain coordinates (may be out of range); returns source index or -1.
+__device__ inline int src_coord(int v, int Hu, int ups, int reflect) {
+  if (v < 0) {
+    if (!reflect) return -1;
+    v = -v;
+  } else if (v >= Hu) {
+    if (!reflect) return -1;
+    v = 2 * Hu - 2 - v;
+  }
+  return v >> ups;
+}

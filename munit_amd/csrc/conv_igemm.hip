@@ -1,0 +1,523 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32.  One kernel serves
+//   * forward conv (reflect/zero pad, stride 1/2, optional fused nearest x2 upsample of
+//     the input, fused bias + activation)            -- networks.py:695-701, 532-546
+//   * backward-data, as a stride-1 zero-padded correlation of dy with re-laid-out weights,
+//     one launch "phase" per (row,col) residue for strided convs (a transposed conv);
+//     the adjoint of the reflect padding / upsample is applied by fold_kernel.
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin with k = (kh*KW+kw)*Cin+ci.
+// NHWC makes every K-tile of 32 channels one contiguous 128-byte run per output pixel.
+// Tile: 128 (M) x BN (N) x 32 (K), 256 threads = 4 waves in 2x2, each wave 64 x BN/2
+// as 32x32 MFMA tiles.  A/B tiles are staged through LDS as [row][36] floats (pad 4 =>
+// conflict-free ds_read_b128 for the MFMA operand fetch: one b128 feeds 4 MFMA k-steps).
+// Global loads for tile k+1 are issued before the MFMAs of tile k (register prefetch).
+#include "common.h"
+
+namespace {
+
+struct IgemmParams {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int B, H, W, Cin;   // source tensor
+  int Hu, Wu, ups;    // upsampled extent (H << ups)
+  int Ho, Wo, Cout;   // output grid / GEMM N
+  int KH, KW, stride, pad, reflect;
+  int Ktot;           // KH*KW*Cin
+  long long w_row;    // floats between two output-channel rows of w
+  long long y_sb;     // output strides (floats)
+  long long y_sh;
+  int y_sw;
+  int M;              // B*Ho*Wo
+  int act;
+  float slope;
+  // phase launches (backward-data of strided convs): blockIdx.y = pa*ps + pb
+  int ps;                  // phases per axis (1 for everything else)
+  long long w_phase;       // floats between the weights of two phases
+  long long y_phase_row;   // output offset per pa
+  int y_phase_col;         // output offset per pb
+  int n_tiles;             // tiles along N
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+// ROLE only names the instantiation (0 = forward, 1 = backward-data) so profiles attribute
+// time to the right pass; the code is the same.
+template <int BN, bool ALIGNED, int ROLE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
+  constexpr int NT = BN / 64;       // 32-wide MFMA tiles along N per wave
+  constexpr int WN = BN / 2;        // N extent per wave
+  constexpr int BROWS = BN / 32;    // weight rows per loader thread
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tile = blockIdx.x;
+  const int n_tile = tile % p.n_tiles;
+  const int m_tile = tile / p.n_tiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+
+  const float* __restrict__ xg = p.x;
+  const float* __restrict__ wg = p.w;
+  float* __restrict__ yg = p.y;
+  if (p.ps > 1) {
+    const int pa = blockIdx.y / p.ps, pb = blockIdx.y % p.ps;
+    wg += (long long)blockIdx.y * p.w_phase;
+    yg += (long long)pa * p.y_phase_row + (long long)pb * p.y_phase_col;
+  }
+
+  // ---- loader coordinates ----
+  const int c4 = tid & 7;   // float4 column inside the 32-wide K tile
+  const int r0 = tid >> 3;  // 0..31
+  const int HoWo = p.Ho * p.Wo;
+  long long a_base[4];
+  int a_ih0[4], a_iw0[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    int b = mm / HoWo;
+    int rem = mm - b * HoWo;
+    int oh = rem / p.Wo;
+    int ow = rem - oh * p.Wo;
+    a_base[i] = (long long)b * p.H * p.W;
+    a_ih0[i] = oh * p.stride - p.pad;
+    a_iw0[i] = ow * p.stride - p.pad;
+  }
+
+  f32x4 ra[4], rb[BROWS];
+  int kh = 0, kw = 0, c0 = 0;  // aligned-mode K iterator
+  const int nk = (p.Ktot + BK - 1) / BK;
+
+  auto load_tile = [&](int kt) {
+    if constexpr (ALIGNED) {
+      const int tap = kh * p.KW + kw;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ih = src_coord(a_ih0[i] + kh, p.Hu, p.ups, p.reflect);
+        int iw = src_coord(a_iw0[i] + kw, p.Wu, p.ups, p.reflect);
+        bool ok = a_ok[i] && ih >= 0 && iw >= 0;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* ptr = xg + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + c0 + c4 * 4;
+          v = *reinterpret_cast<const f32x4*>(ptr);
+        }
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        int n = n0 + r0 + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.Cout) {
+          const float* ptr = wg + (long long)n * p.w_row + (long long)tap * p.Cin + c0 + c4 * 4;
+          v = *reinterpret_cast<const f32x4*>(ptr);
+        }
+        rb[i] = v;
+      }
+      c0 += BK;
+      if (c0 >= p.Cin) {
+        c0 = 0;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
+    } else {
+      int ekh[4], ekw[4], eci[4];
+      bool eok[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int k = kt * BK + c4 * 4 + e;
+        eok[e] = k < p.Ktot;
+        int kk = eok[e] ? k : 0;
+        int tap = kk / p.Cin;
+        eci[e] = kk - tap * p.Cin;
+        ekh[e] = tap / p.KW;
+        ekw[e] = tap - ekh[e] * p.KW;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ih = src_coord(a_ih0[i] + ekh[e], p.Hu, p.ups, p.reflect);
+          int iw = src_coord(a_iw0[i] + ekw[e], p.Wu, p.ups, p.reflect);
+          bool ok = a_ok[i] && eok[e] && ih >= 0 && iw >= 0;
+          float s = 0.f;
+          if (ok) s = xg[(a_base[i] + (long long)ih * p.W + iw) * p.Cin + eci[e]];
+          v[e] = s;
+        }
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        int n = n0 + r0 + 32 * i;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int k = kt * BK + c4 * 4 + e;
+          float s = 0.f;
+          if (n < p.Cout && k < p.Ktot) s = wg[(long long)n * p.w_row + k];
+          v[e] = s;
+        }
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      f32x4 a[2], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        b[nt] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + nt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave) ----
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn * WN + nt * 32 + (lane & 31);
+    const bool n_ok = n < p.Cout;
+    const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int m = m0 + row;
+        if (m < p.M && n_ok) {
+          int b = m / HoWo;
+          int rem = m - b * HoWo;
+          int oh = rem / p.Wo;
+          int ow = rem - oh * p.Wo;
+          long long off = (long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n;
+          yg[off] = apply_act(acc[mt][nt][r] + bv, p.act, p.slope);
+        }
+      }
+    }
+  }
+}
+
+// Re-lay-out weights for backward-data.  w: [Cout][KH][KW][Cin]  ->
+// wt: [ps*ps phases][Cin][T][T][Cout] with T = K/ps and, for phase (pa,pb), tap (t,r):
+//   wt[ph][ci][t][r][co] = w[co][pa + ps*(T-1-t)][pb + ps*(T-1-r)][ci]
+__global__ void wt_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int KH,
+                                int KW, int Cin, int ps) {
+  const int TH = KH / ps, TW = KW / ps;
+  const long long per_phase = (long long)Cin * TH * TW * Cout;
+  const long long total = per_phase * ps * ps;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r_ = i;
+    int co = (int)(r_ % Cout); r_ /= Cout;
+    int r = (int)(r_ % TW); r_ /= TW;
+    int t = (int)(r_ % TH); r_ /= TH;
+    int ci = (int)(r_ % Cin); r_ /= Cin;
+    int ph = (int)r_;
+    int pa = ph / ps, pb = ph % ps;
+    int kh = pa + ps * (TH - 1 - t);
+    int kw = pb + ps * (TW - 1 - r);
+    wt[i] = w[(((long long)co * KH + kh) * KW + kw) * Cin + ci];
+  }
+}
+
+// Adjoint of (nearest x2 upsample) + (reflect | zero pad): gather-sum the padded-domain
+// gradient g[B][Hq][Wq][C] (rows/cols beyond Hq/Wq are zero) into dx[B][H][W][C].
+__global__ void fold_kernel(const float* __restrict__ g, const float* __restrict__ add,
+                            float* __restrict__ dx, int B, int H, int W, int C, int ups, int pad,
+                            int reflect, int Hq, int Wq) {
+  const int C4 = C >> 2;
+  const long long total = (long long)B * H * W * C4;
+  const int Hu = H << ups, Wu = W << ups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r_ = i;
+    int c4 = (int)(r_ % C4); r_ /= C4;
+    int iw = (int)(r_ % W); r_ /= W;
+    int ih = (int)(r_ % H); r_ /= H;
+    int b = (int)r_;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int nu = 1 << ups;
+    for (int du = 0; du < nu; ++du) {
+      int hu = (ih << ups) + du;
+      int qr[3], nr = 0;
+      qr[nr++] = hu + pad;
+      if (reflect) {
+        if (hu >= 1 && hu <= pad) qr[nr++] = pad - hu;
+        if (hu >= Hu - 1 - pad && hu <= Hu - 2) qr[nr++] = 2 * Hu - 2 - hu + pad;
+      }
+      for (int dv = 0; dv < nu; ++dv) {
+        int wu = (iw << ups) + dv;
+        int qc[3], nc = 0;
+        qc[nc++] = wu + pad;
+        if (reflect) {
+          if (wu >= 1 && wu <= pad) qc[nc++] = pad - wu;
+          if (wu >= Wu - 1 - pad && wu <= Wu - 2) qc[nc++] = 2 * Wu - 2 - wu + pad;
+        }
+        for (int a = 0; a < nr; ++a) {
+          if (qr[a] >= Hq) continue;
+          for (int c = 0; c < nc; ++c) {
+            if (qc[c] >= Wq) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(
+                g + (((long long)b * Hq + qr[a]) * Wq + qc[c]) * C + c4 * 4);
+            s += v;
+          }
+        }
+      }
+    }
+    if (add != nullptr) s += *reinterpret_cast<const f32x4*>(add + i * 4);
+    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+  }
+}
+
+// scalar-channel variant of fold_kernel for C % 4 != 0 (3-channel images)
+__global__ void fold_scalar_kernel(const float* __restrict__ g, const float* __restrict__ add,
+                                   float* __restrict__ dx, int B, int H, int W, int C, int ups, int pad,
+                                   int reflect, int Hq, int Wq) {
+  const long long total = (long long)B * H * W * C;
+  const int Hu = H << ups, Wu = W << ups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r_ = i;
+    int c = (int)(r_ % C); r_ /= C;
+    int iw = (int)(r_ % W); r_ /= W;
+    int ih = (int)(r_ % H); r_ /= H;
+    int b = (int)r_;
+    float s = 0.f;
+    const int nu = 1 << ups;
+    for (int du = 0; du < nu; ++du) {
+      int hu = (ih << ups) + du;
+      int qr[3], nr = 0;
+      qr[nr++] = hu + pad;
+      if (reflect) {
+        if (hu >= 1 && hu <= pad) qr[nr++] = pad - hu;
+        if (hu >= Hu - 1 - pad && hu <= Hu - 2) qr[nr++] = 2 * Hu - 2 - hu + pad;
+      }
+      for (int dv = 0; dv < nu; ++dv) {
+        int wu = (iw << ups) + dv;
+        int qc[3], nc = 0;
+        qc[nc++] = wu + pad;
+        if (reflect) {
+          if (wu >= 1 && wu <= pad) qc[nc++] = pad - wu;
+          if (wu >= Wu - 1 - pad && wu <= Wu - 2) qc[nc++] = 2 * Wu - 2 - wu + pad;
+        }
+        for (int a = 0; a < nr; ++a) {
+          if (qr[a] >= Hq) continue;
+          for (int cc = 0; cc < nc; ++cc) {
+            if (qc[cc] >= Wq) continue;
+            s += g[(((long long)b * Hq + qr[a]) * Wq + qc[cc]) * C + c];
+          }
+        }
+      }
+    }
+    if (add != nullptr) s += add[i];
+    dx[i] = s;
+  }
+}
+
+template <int ROLE>
+int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
+  const bool aligned = (p.Cin % BK == 0) && (p.w_row % 4 == 0);
+  const int bn = p.Cout <= 64 ? 64 : 128;
+  IgemmParams q = p;
+  q.n_tiles = cdiv(p.Cout, bn);
+  const int m_tiles = cdiv(p.M, BM);
+  dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
+  dim3 block(256);
+  if (bn == 64) {
+    if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<64, false, ROLE>), grid, block, 0, st, q);
+  } else {
+    if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, false, ROLE>), grid, block, 0, st, q);
+  }
+  MUNIT_CHECK_LAUNCH("conv_igemm");
+  return MUNIT_OK;
+}
+
+int check_desc(const munit_conv_desc* d) {
+  MUNIT_CHECK_ARG(d != nullptr, "conv: null descriptor");
+  MUNIT_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims");
+  MUNIT_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
+  MUNIT_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv: upsample must be 0 or 1");
+  MUNIT_CHECK_ARG(d->pad_mode == MUNIT_PAD_ZERO || d->pad_mode == MUNIT_PAD_REFLECT, "conv: bad pad mode");
+  const int Hu = d->H << d->upsample, Wu = d->W << d->upsample;
+  if (d->pad_mode == MUNIT_PAD_REFLECT)
+    MUNIT_CHECK_ARG(d->pad < Hu && d->pad < Wu, "conv: reflect pad %d needs input > pad (got %dx%d)", d->pad, Hu, Wu);
+  MUNIT_CHECK_ARG(Hu + 2 * d->pad >= d->KH && Wu + 2 * d->pad >= d->KW, "conv: kernel larger than padded input");
+  MUNIT_CHECK_ARG((long long)d->B * Hu * Wu < (1ll << 31) / 4, "conv: too many pixels for 32-bit tile indices");
+  return MUNIT_OK;
+}
+
+}  // namespace
+
+extern "C" int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  *Ho = ((d->H << d->upsample) + 2 * d->pad - d->KH) / d->stride + 1;
+  *Wo = ((d->W << d->upsample) + 2 * d->pad - d->KW) / d->stride + 1;
+  return MUNIT_OK;
+}
+
+extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w,
+                                const float* bias, float* y, munit_stream_t stream) {
+  int Ho, Wo;
+  int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
+  if (rc) return rc;
+  MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  IgemmParams p{};
+  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.ups = d->upsample; p.Hu = d->H << p.ups; p.Wu = d->W << p.ups;
+  p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  p.Ktot = d->KH * d->KW * d->Cin;
+  p.w_row = p.Ktot;
+  p.y_sw = d->Cout;
+  p.y_sh = (long long)Wo * d->Cout;
+  p.y_sb = (long long)Ho * Wo * d->Cout;
+  p.M = d->B * Ho * Wo;
+  p.act = d->act; p.slope = d->slope;
+  p.ps = 1;
+  return launch_igemm<0>(p, 1, (hipStream_t)stream);
+}
+
+namespace {
+struct DgradPlan {
+  int Ho, Wo, ps, TH, TW, Hq, Wq;
+  bool direct;  // write dx directly (no pad / upsample / add): 1x1 convs, linear layers
+  size_t wt_bytes, g_bytes;
+};
+int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
+  int rc = munit_conv2d_out_hw(d, &pl->Ho, &pl->Wo);
+  if (rc) return rc;
+  MUNIT_CHECK_ARG(d->KH % d->stride == 0 && d->KW % d->stride == 0,
+                  "conv2d_dgrad: kernel %dx%d not a multiple of stride %d", d->KH, d->KW, d->stride);
+  pl->ps = d->stride;
+  pl->TH = d->KH / d->stride;
+  pl->TW = d->KW / d->stride;
+  pl->Hq = d->stride * (pl->Ho + pl->TH - 1);
+  pl->Wq = d->stride * (pl->Wo + pl->TW - 1);
+  pl->direct = d->pad == 0 && d->upsample == 0 && pl->Hq == d->H && pl->Wq == d->W;
+  pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
+  pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
+  return MUNIT_OK;
+}
+}  // namespace
+
+extern "C" size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d) {
+  DgradPlan pl;
+  if (plan_dgrad(d, &pl)) return 0;
+  return pl.wt_bytes + pl.g_bytes;
+}
+
+extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w,
+                                  const float* add, float* dx, void* ws, size_t ws_bytes,
+                                  munit_stream_t stream) {
+  DgradPlan pl;
+  int rc = plan_dgrad(d, &pl);
+  if (rc) return rc;
+  MUNIT_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
+  if (ws_bytes < pl.wt_bytes + pl.g_bytes) {
+    munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes);
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* wt = reinterpret_cast<float*>(ws);
+  float* g = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.wt_bytes);
+  const bool direct = pl.direct && add == nullptr;
+  {
+    long long total = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(wt_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, wt, d->Cout, d->KH, d->KW,
+                       d->Cin, pl.ps);
+    MUNIT_CHECK_LAUNCH("wt_dgrad");
+  }
+  IgemmParams p{};
+  p.x = dy; p.w = wt; p.bias = nullptr; p.y = direct ? dx : g;
+  p.B = d->B; p.H = pl.Ho; p.W = pl.Wo; p.Cin = d->Cout;
+  p.ups = 0; p.Hu = pl.Ho; p.Wu = pl.Wo;
+  p.Ho = pl.Ho + pl.TH - 1; p.Wo = pl.Wo + pl.TW - 1; p.Cout = d->Cin;
+  p.KH = pl.TH; p.KW = pl.TW; p.stride = 1; p.pad = pl.TH - 1;  // TH == TW for every layer here
+  MUNIT_CHECK_ARG(pl.TH == pl.TW, "conv2d_dgrad: non-square kernels are not supported");
+  p.reflect = 0;
+  p.Ktot = pl.TH * pl.TW * d->Cout;
+  p.w_row = p.Ktot;
+  p.y_sw = pl.ps * d->Cin;
+  p.y_sh = (long long)pl.ps * pl.Wq * d->Cin;
+  p.y_sb = (long long)pl.Hq * pl.Wq * d->Cin;
+  p.M = d->B * p.Ho * p.Wo;
+  p.act = MUNIT_ACT_NONE; p.slope = 0.f;
+  p.ps = pl.ps;
+  p.w_phase = (long long)d->Cin * p.Ktot;
+  p.y_phase_row = (long long)pl.Wq * d->Cin;
+  p.y_phase_col = d->Cin;
+  rc = launch_igemm<1>(p, pl.ps * pl.ps, st);
+  if (rc) return rc;
+  if (!direct) {
+    const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+    if (d->Cin % 4 == 0) {
+      long long total = (long long)d->B * d->H * d->W * (d->Cin / 4);
+      int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+      hipLaunchKernelGGL(fold_kernel, dim3(blocks), dim3(256), 0, st, g, add, dx, d->B, d->H, d->W, d->Cin,
+                         d->upsample, d->pad, reflect, pl.Hq, pl.Wq);
+    } else {
+      long long total = (long long)d->B * d->H * d->W * d->Cin;
+      int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+      hipLaunchKernelGGL(fold_scalar_kernel, dim3(blocks), dim3(256), 0, st, g, add, dx, d->B, d->H, d->W,
+                         d->Cin, d->upsample, d->pad, reflect, pl.Hq, pl.Wq);
+    }
+    MUNIT_CHECK_LAUNCH("fold");
+  }
+  return MUNIT_OK;
+}

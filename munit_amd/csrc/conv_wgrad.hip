@@ -1,0 +1,289 @@
+// Backward-weight of the convolutions (autograd of networks.py:691-696) as a split-K
+// MFMA GEMM:  dw[co][k] = sum_m dy[m][co] * A[m][k],  k = (kh*KW+kw)*Cin+ci,
+// A = the same on-the-fly im2col gather the forward uses (reflect/zero pad, stride,
+// fused nearest upsample).  The reduction runs over m = output pixels (up to 524288*B),
+// so the grid is (k tiles) x (cout tiles) x (pixel splits); each split writes a partial
+// slab and slab_reduce_kernel sums them in a fixed order (deterministic, no atomics).
+// The bias gradient (column sums of dy) rides along in the k-tile-0 blocks.
+//
+// Tile: BC (cout) x 128 (k) accumulators, 32 pixels per step.  dy and A tiles are staged
+// in LDS as [pixel][channel]; the MFMA operand fetch is one ds_read_b32 per lane
+// (lanes 0-31 = consecutive channels => conflict-free).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* slab;       // [nsplit][Cout][Ktot]
+  float* bias_slab;  // [nsplit][Cout] or null
+  int B, H, W, Cin, Hu, Wu, ups;
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad, reflect;
+  int Ktot, M;
+  int pix_per_split;  // multiple of 32
+};
+
+constexpr int WK = 128;  // k columns per block
+constexpr int WP = 32;   // pixels per step
+
+template <int BC, bool ALIGNED>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  constexpr int MT = BC / 64;  // 32-row MFMA tiles per wave along cout (wave grid 2x2)
+  constexpr int WC = BC / 2;
+  constexpr int DQ = BC / 4;   // float4 per dy row
+  constexpr int DROWS = WP * DQ / 256;  // dy rows per loader thread (4 for BC=128, 2 for 64)
+  __shared__ __attribute__((aligned(16))) float Ds[WP * BC];
+  __shared__ __attribute__((aligned(16))) float Xs[WP * WK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kc0 = blockIdx.x * WK;
+  const int co0 = blockIdx.y * BC;
+  const int split = blockIdx.z;
+  const int m_begin = split * p.pix_per_split;
+  const int m_end = min(p.M, m_begin + p.pix_per_split);
+  const int HoWo = p.Ho * p.Wo;
+
+  // X-tile loader: 32 pixels x 128 k columns = 32 float4 per row; thread -> (row = tid>>5 + 8i, q = tid&31)
+  const int xq = tid & 31;
+  const int xr0 = tid >> 5;
+  int ekh[4], ekw[4], eci[4];
+  bool eok[4];
+  if constexpr (ALIGNED) {
+    int k = kc0 + xq * 4;
+    eok[0] = k < p.Ktot;
+    int kk = eok[0] ? k : 0;
+    int tap = kk / p.Cin;
+    eci[0] = kk - tap * p.Cin;
+    ekh[0] = tap / p.KW;
+    ekw[0] = tap - ekh[0] * p.KW;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int k = kc0 + xq * 4 + e;
+      eok[e] = k < p.Ktot;
+      int kk = eok[e] ? k : 0;
+      int tap = kk / p.Cin;
+      eci[e] = kk - tap * p.Cin;
+      ekh[e] = tap / p.KW;
+      ekw[e] = tap - ekh[e] * p.KW;
+    }
+  }
+  // dy-tile loader: thread -> (row = tid / DQ + (256/DQ) * i, q = tid % DQ)
+  const int dq = tid % DQ;
+  const int dr0 = tid / DQ;
+
+  f32x4 rx[4], rd[DROWS];
+
+  auto load_tiles = [&](int mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = mbase + xr0 + 8 * i;
+      bool mok = m < m_end;
+      int mm = mok ? m : 0;
+      int b = mm / HoWo;
+      int rem = mm - b * HoWo;
+      int oh = rem / p.Wo;
+      int ow = rem - oh * p.Wo;
+      long long base = (long long)b * p.H * p.W;
+      int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (ALIGNED) {
+        int ih = src_coord(ih0 + ekh[0], p.Hu, p.ups, p.reflect);
+        int iw = src_coord(iw0 + ekw[0], p.Wu, p.ups, p.reflect);
+        if (mok && eok[0] && ih >= 0 && iw >= 0)
+          v = *reinterpret_cast<const f32x4*>(p.x + (base + (long long)ih * p.W + iw) * p.Cin + eci[0]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ih = src_coord(ih0 + ekh[e], p.Hu, p.ups, p.reflect);
+          int iw = src_coord(iw0 + ekw[e], p.Wu, p.ups, p.reflect);
+          float s = 0.f;
+          if (mok && eok[e] && ih >= 0 && iw >= 0) s = p.x[(base + (long long)ih * p.W + iw) * p.Cin + eci[e]];
+          v[e] = s;
+        }
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < DROWS; ++i) {
+      int m = mbase + dr0 + (256 / DQ) * i;
+      int co = co0 + dq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const float* ptr = p.dy + (long long)m * p.Cout + co;
+        if ((p.Cout & 3) == 0) {
+          if (co < p.Cout) v = *reinterpret_cast<const f32x4*>(ptr);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) v[e] = ptr[e];
+        }
+      }
+      rd[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Xs[(xr0 + 8 * i) * WK + xq * 4]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < DROWS; ++i)
+      *reinterpret_cast<f32x4*>(&Ds[(dr0 + (256 / DQ) * i) * BC + dq * 4]) = rd[i];
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;  // bias column sum: thread tid < BC owns channel co0 + tid
+  const bool do_bias = p.bias_slab != nullptr && blockIdx.x == 0;
+
+  if (m_begin < m_end) {
+    load_tiles(m_begin);
+    store_tiles();
+  }
+  __syncthreads();
+  const int fr = lane & 31;
+  const int fk = lane >> 5;
+  for (int mb = m_begin; mb < m_end; mb += WP) {
+    const bool more = mb + WP < m_end;
+    if (more) load_tiles(mb + WP);
+#pragma unroll
+    for (int kk = 0; kk < WP; kk += 2) {
+      float a[MT], b[2];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[t] = Ds[(kk + fk) * BC + wm * WC + t * 32 + fr];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = Xs[(kk + fk) * WK + wn * 64 + t * 32 + fr];
+#pragma unroll
+      for (int s = 0; s < MT; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[s][t], 0, 0, 0);
+    }
+    if (do_bias && tid < BC) {
+#pragma unroll 8
+      for (int r = 0; r < WP; ++r) bsum += Ds[r * BC + tid];
+    }
+    __syncthreads();
+    if (more) store_tiles();
+    __syncthreads();
+  }
+
+  // ---- write the partial tile: slab[split][co][k] ----
+  float* out = p.slab + (long long)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = kc0 + wn * 64 + t * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int co = co0 + wm * WC + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[s][t][r];
+      }
+    }
+  }
+  if (do_bias && tid < BC && co0 + tid < p.Cout) p.bias_slab[(long long)split * p.Cout + co0 + tid] = bsum;
+}
+
+// dst[i] = beta*dst[i] + sum_s slab[s][i]
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, long long n,
+                                   int nsplit, float beta) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * n + i];
+    dst[i] = (beta != 0.f ? beta * dst[i] : 0.f) + s;
+  }
+}
+
+struct WgradPlan {
+  int Ho, Wo, M, Ktot, bc, k_tiles, c_tiles, nsplit, pix_per_split;
+  size_t slab_bytes, bias_bytes;
+};
+
+int plan_wgrad(const munit_conv_desc* d, WgradPlan* pl) {
+  int rc = munit_conv2d_out_hw(d, &pl->Ho, &pl->Wo);
+  if (rc) return rc;
+  pl->M = d->B * pl->Ho * pl->Wo;
+  pl->Ktot = d->KH * d->KW * d->Cin;
+  pl->bc = d->Cout <= 64 ? 64 : 128;
+  pl->k_tiles = cdiv(pl->Ktot, WK);
+  pl->c_tiles = cdiv(d->Cout, pl->bc);
+  const int tiles = pl->k_tiles * pl->c_tiles;
+  // aim for ~1024 blocks, at least 128 pixels per split, at most 512 splits
+  int want = cdiv(1024, tiles);
+  int max_by_pix = std::max(1, pl->M / 128);
+  int ns = std::max(1, std::min(std::min(want, max_by_pix), 512));
+  int pps = cdiv(pl->M, ns);
+  pps = (pps + WP - 1) / WP * WP;
+  ns = cdiv(pl->M, pps);
+  pl->nsplit = ns;
+  pl->pix_per_split = pps;
+  pl->slab_bytes = align_up((size_t)ns * d->Cout * pl->Ktot * sizeof(float), 256);
+  pl->bias_bytes = align_up((size_t)ns * d->Cout * sizeof(float), 256);
+  return MUNIT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
+  WgradPlan pl;
+  if (plan_wgrad(d, &pl)) return 0;
+  return pl.slab_bytes + pl.bias_bytes;
+}
+
+extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
+                                  float* db, float beta, void* ws, size_t ws_bytes,
+                                  munit_stream_t stream) {
+  WgradPlan pl;
+  int rc = plan_wgrad(d, &pl);
+  if (rc) return rc;
+  MUNIT_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  if (ws_bytes < pl.slab_bytes + pl.bias_bytes) {
+    munit_set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.slab_bytes + pl.bias_bytes);
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WgradParams p{};
+  p.x = x; p.dy = dy;
+  p.slab = reinterpret_cast<float*>(ws);
+  p.bias_slab = db ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.slab_bytes) : nullptr;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.ups = d->upsample; p.Hu = d->H << p.ups; p.Wu = d->W << p.ups;
+  p.Ho = pl.Ho; p.Wo = pl.Wo; p.Cout = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  p.Ktot = pl.Ktot; p.M = pl.M; p.pix_per_split = pl.pix_per_split;
+  const bool aligned = d->Cin % 4 == 0;
+  dim3 grid((unsigned)pl.k_tiles, (unsigned)pl.c_tiles, (unsigned)pl.nsplit);
+  if (pl.bc == 64) {
+    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(256), 0, st, p);
+  }
+  MUNIT_CHECK_LAUNCH("conv_wgrad");
+  {
+    long long n = (long long)d->Cout * pl.Ktot;
+    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, n, pl.nsplit, beta);
+    MUNIT_CHECK_LAUNCH("slab_reduce(dw)");
+  }
+  if (db) {
+    int blocks = cdiv(d->Cout, 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.bias_slab, db,
+                       (long long)d->Cout, pl.nsplit, beta);
+    MUNIT_CHECK_LAUNCH("slab_reduce(db)");
+  }
+  return MUNIT_OK;
+}

@@ -1,0 +1,563 @@
+// Normalisation layers of the MUNIT generator, NHWC, fp32, HBM-bound:
+//   instance norm / AdaIN  (networks.py:657, 810-848)   per-(b,c) stats over H*W
+//   MUNIT LayerNorm        (networks.py:851-878)        per-sample stats over C*H*W
+// Every pass is two kernels: a partial-statistics kernel over (pixel split, sample) blocks
+// -- per-thread fp32 accumulators over a channel quad, wavefront/LDS reduction across the
+// pixel lanes of the block -- and an apply kernel that folds the split partials in its
+// prologue (kept in LDS) and streams float4s.  Sums are taken relative to a pivot (the
+// first element of the plane) so the variance does not cancel catastrophically.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_SPLIT = 64;
+
+// layout of the thread block over an NHWC plane: QB channel-quads x PL pixel lanes
+struct Lay {
+  int CQ;  // C/4
+  int QB;  // quads handled side by side (<= 256)
+  int PL;  // pixel lanes
+};
+__host__ __device__ inline Lay make_lay(int C) {
+  Lay l;
+  l.CQ = C >> 2;
+  l.QB = l.CQ < NT ? l.CQ : NT;
+  l.PL = NT / l.QB;
+  return l;
+}
+
+inline int pick_split(int B, int HW) {
+  // enough blocks to fill 256 CUs a few times, at least 64 pixels per split
+  int s = std::max(1, std::min(MAX_SPLIT, 2048 / std::max(1, B)));
+  s = std::min(s, std::max(1, HW / 64));
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// instance norm
+// ---------------------------------------------------------------------------------------
+// partial[b][split][2][C] : sum(x - pivot), sum((x - pivot)^2), pivot = x[b][0][c]
+__global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                      int HW, int C, int nsplit) {
+  extern __shared__ float sm[];  // [PL][QB*4][2]
+  const Lay L = make_lay(C);
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const float* xb = x + (long long)b * HW * C;
+  for (int qq = q; qq < L.CQ; qq += L.QB) {
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (pl < L.PL) {
+      const f32x4 piv = *reinterpret_cast<const f32x4*>(xb + qq * 4);
+      for (int p = p0 + pl; p < p1; p += L.PL) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C + qq * 4) - piv;
+        s1 += v;
+        s2 += v * v;
+      }
+      float* d = sm + ((pl * L.QB + q) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+    }
+    __syncthreads();
+    if (pl == 0) {
+      for (int l = 1; l < L.PL; ++l) {
+        const float* d = sm + ((l * L.QB + q) * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
+      }
+      float* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+      *reinterpret_cast<f32x4*>(o) = s1;
+      *reinterpret_cast<f32x4*>(o + C) = s2;
+    }
+    __syncthreads();
+  }
+}
+
+// y = act((x-mean)*rstd*w + b) + residual ; writes stats[b][c] = (mean, rstd) from split 0
+__global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ partial, float* __restrict__ stats,
+                                                      int HW, int C, int nsplit, const float* __restrict__ adain,
+                                                      int ad_ld, int w_off, int b_off,
+                                                      const float* __restrict__ residual, int relu, float eps) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  float* scale = sm;
+  float* shift = sm + C;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const float* xb = x + (long long)b * HW * C;
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+      const float* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+      s1 += o[c];
+      s2 += o[C + c];
+    }
+    const float inv_n = 1.f / (float)HW;
+    const float d = s1 * inv_n;
+    const float mean = xb[c] + d;
+    float var = s2 * inv_n - d * d;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float w = 1.f, bb = 0.f;
+    if (adain != nullptr) {
+      w = adain[(long long)b * ad_ld + w_off + c];
+      bb = adain[(long long)b * ad_ld + b_off + c];
+    }
+    scale[c] = rstd * w;
+    shift[c] = bb - mean * rstd * w;
+    if (sp == 0) {
+      stats[((long long)b * C + c) * 2] = mean;
+      stats[((long long)b * C + c) * 2 + 1] = rstd;
+    }
+  }
+  __syncthreads();
+  const int CQ = C >> 2;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long i0 = (long long)p0 * CQ, i1 = (long long)p1 * CQ;
+  const long long base = (long long)b * HW * C;
+  for (long long i = i0 + threadIdx.x; i < i1; i += NT) {
+    const int q = (int)(i % CQ);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+    v = v * sc + sh;
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (residual != nullptr) v += *reinterpret_cast<const f32x4*>(residual + base + i * 4);
+    *reinterpret_cast<f32x4*>(y + base + i * 4) = v;
+  }
+}
+
+// backward partials: partial[b][split][2][C] : sum(g), sum(g*xhat), g = dy * relu'(pre)
+__global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats, float* __restrict__ partial,
+                                                          int HW, int C, int nsplit, const float* __restrict__ adain,
+                                                          int ad_ld, int w_off, int b_off, int relu) {
+  extern __shared__ float sm[];
+  const Lay L = make_lay(C);
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long base = (long long)b * HW * C;
+  for (int qq = q; qq < L.CQ; qq += L.QB) {
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (pl < L.PL) {
+      f32x4 mean, rstd, w, bb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = qq * 4 + e;
+        mean[e] = stats[((long long)b * C + c) * 2];
+        rstd[e] = stats[((long long)b * C + c) * 2 + 1];
+        w[e] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
+        bb[e] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
+      }
+      for (int p = p0 + pl; p < p1; p += L.PL) {
+        const long long o = base + (long long)p * C + qq * 4;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
+        }
+        s1 += g;
+        s2 += g * xh;
+      }
+      float* d = sm + ((pl * L.QB + q) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+    }
+    __syncthreads();
+    if (pl == 0) {
+      for (int l = 1; l < L.PL; ++l) {
+        const float* d = sm + ((l * L.QB + q) * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
+      }
+      float* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+      *reinterpret_cast<f32x4*>(o) = s1;
+      *reinterpret_cast<f32x4*>(o + C) = s2;
+    }
+    __syncthreads();
+  }
+}
+
+// dx = rstd*w*(g - mean(g) - xhat*mean(g*xhat)); d_adain weight = sum(g*xhat), bias = sum(g)
+__global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ partial, float* __restrict__ dx,
+                                                          int HW, int C, int nsplit, const float* __restrict__ adain,
+                                                          float* __restrict__ d_adain, int ad_ld, int w_off, int b_off,
+                                                          int relu) {
+  extern __shared__ float sm[];  // mean[C], rstd[C], w[C], b[C], a1[C], a2[C]
+  float* s_mean = sm;
+  float* s_rstd = sm + C;
+  float* s_w = sm + 2 * C;
+  float* s_b = sm + 3 * C;
+  float* s_a1 = sm + 4 * C;
+  float* s_a2 = sm + 5 * C;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+      const float* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+      a1 += o[c];
+      a2 += o[C + c];
+    }
+    s_mean[c] = stats[((long long)b * C + c) * 2];
+    s_rstd[c] = stats[((long long)b * C + c) * 2 + 1];
+    s_w[c] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
+    s_b[c] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
+    if (sp == 0 && d_adain != nullptr) {
+      d_adain[(long long)b * ad_ld + w_off + c] = a2;
+      d_adain[(long long)b * ad_ld + b_off + c] = a1;
+    }
+    const float inv_n = 1.f / (float)HW;
+    s_a1[c] = a1 * inv_n;
+    s_a2[c] = a2 * inv_n;
+  }
+  __syncthreads();
+  const int CQ = C >> 2;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long i0 = (long long)p0 * CQ, i1 = (long long)p1 * CQ;
+  const long long base = (long long)b * HW * C;
+  for (long long i = i0 + threadIdx.x; i < i1; i += NT) {
+    const int q = (int)(i % CQ);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(s_mean + q * 4);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(s_rstd + q * 4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(s_w + q * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b + q * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a1 + q * 4);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(s_a2 + q * 4);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + base + i * 4) - mean) * rstd;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + base + i * 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 r = rstd * w * (g - a1 - xh * a2);
+    *reinterpret_cast<f32x4*>(dx + base + i * 4) = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// MUNIT LayerNorm
+// ---------------------------------------------------------------------------------------
+__device__ inline float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+
+// partial[b][split][2]: sum(x-pivot), sum((x-pivot)^2), pivot = x[b][0]
+__global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                      long long n_per_sample, int nsplit) {
+  __shared__ float red[NT / 64];
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const float* xb = x + (long long)b * n_per_sample;
+  const long long nq = n_per_sample >> 2;
+  const long long per = (nq + nsplit - 1) / nsplit;
+  const long long q0 = sp * per, q1 = min(nq, q0 + per);
+  const float piv = xb[0];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = v[e] - piv;
+      s1 += d;
+      s2 += d * d;
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    partial[((long long)b * nsplit + sp) * 2] = s1;
+    partial[((long long)b * nsplit + sp) * 2 + 1] = s2;
+  }
+}
+
+__device__ inline void ln_finish(const float* partial, const float* xb, int b, int nsplit, long long n,
+                                 float* mean, float* sigma) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += (double)partial[((long long)b * nsplit + k) * 2];
+    s2 += (double)partial[((long long)b * nsplit + k) * 2 + 1];
+  }
+  const double d = s1 / (double)n;
+  double var = (s2 - s1 * d) / (double)(n - 1);  // unbiased (torch.std default), networks.py:868/871
+  if (var < 0.0) var = 0.0;
+  *mean = (float)((double)xb[0] + d);
+  *sigma = (float)sqrt(var);
+}
+
+__global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ partial, float* __restrict__ stats,
+                                                      int HW, int C, int nsplit, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int relu, float eps) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  float* scale = sm;
+  float* shift = sm + C;
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const long long n = (long long)HW * C;
+  const float* xb = x + (long long)b * n;
+  float mean, sigma;
+  ln_finish(partial, xb, b, nsplit, n, &mean, &sigma);
+  const float inv = 1.f / (sigma + eps);
+  if (sp == 0 && threadIdx.x == 0) {
+    stats[b * 2] = mean;
+    stats[b * 2 + 1] = sigma;
+  }
+  for (int c = threadIdx.x; c < C; c += NT) {
+    scale[c] = inv * gamma[c];
+    shift[c] = beta[c] - mean * inv * gamma[c];
+  }
+  __syncthreads();
+  const int CQ = C >> 2;
+  const long long nq = n >> 2;
+  const long long per = (nq + nsplit - 1) / nsplit;
+  const long long q0 = sp * per, q1 = min(nq, q0 + per);
+  for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
+    const int q = (int)(i % CQ);
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
+    v = v * *reinterpret_cast<const f32x4*>(scale + q * 4) + *reinterpret_cast<const f32x4*>(shift + q * 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(y + (long long)b * n + i * 4) = v;
+  }
+}
+
+// backward partials. per (b, split): chan[2][C] = sum(g*xn), sum(g) per channel (g = dy*relu');
+// samp[2] = sum(g*gamma), sum(g*gamma*xn).
+// cpart layout [b][split][2][C], spart layout [b][split][2]
+__global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats, float* __restrict__ cpart,
+                                                          float* __restrict__ spart, int HW, int C, int nsplit,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu, float eps) {
+  extern __shared__ float sm[];  // [PL][QB*4][2]
+  __shared__ float red[NT / 64];
+  const Lay L = make_lay(C);
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long base = (long long)b * HW * C;
+  const float mean = stats[b * 2];
+  const float inv = 1.f / (stats[b * 2 + 1] + eps);
+  float t1 = 0.f, t2 = 0.f;
+  for (int qq = q; qq < L.CQ; qq += L.QB) {
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (pl < L.PL) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + qq * 4);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + qq * 4);
+      for (int p = p0 + pl; p < p1; p += L.PL) {
+        const long long o = base + (long long)p * C + qq * 4;
+        const f32x4 xn = (*reinterpret_cast<const f32x4*>(x + o) - mean) * inv;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
+        }
+        s1 += g * xn;
+        s2 += g;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t1 += s2[e] * gm[e];
+        t2 += s1[e] * gm[e];
+      }
+      float* d = sm + ((pl * L.QB + q) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+    }
+    __syncthreads();
+    if (pl == 0) {
+      for (int l = 1; l < L.PL; ++l) {
+        const float* d = sm + ((l * L.QB + q) * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
+      }
+      float* o = cpart + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+      *reinterpret_cast<f32x4*>(o) = s1;
+      *reinterpret_cast<f32x4*>(o + C) = s2;
+    }
+    __syncthreads();
+  }
+  t1 = block_sum(t1, red);
+  t2 = block_sum(t2, red);
+  if (threadIdx.x == 0) {
+    spart[((long long)b * nsplit + sp) * 2] = t1;
+    spart[((long long)b * nsplit + sp) * 2 + 1] = t2;
+  }
+}
+
+// dx = inv*(h - S1/N) - S2*xn/((N-1)*sigma), h = g*gamma
+__global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ spart, float* __restrict__ dx,
+                                                          int HW, int C, int nsplit, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu, float eps) {
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const long long n = (long long)HW * C;
+  const float mean = stats[b * 2];
+  const float sigma = stats[b * 2 + 1];
+  const float inv = 1.f / (sigma + eps);
+  double S1 = 0.0, S2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    S1 += (double)spart[((long long)b * nsplit + k) * 2];
+    S2 += (double)spart[((long long)b * nsplit + k) * 2 + 1];
+  }
+  const float c1 = (float)(S1 / (double)n);
+  const float c2 = sigma > 0.f ? (float)(S2 / ((double)(n - 1) * (double)sigma)) : 0.f;
+  const int CQ = C >> 2;
+  const long long nq = n >> 2;
+  const long long per = (nq + nsplit - 1) / nsplit;
+  const long long q0 = sp * per, q1 = min(nq, q0 + per);
+  const long long base = (long long)b * n;
+  for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
+    const int q = (int)(i % CQ);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
+    const f32x4 xn = (*reinterpret_cast<const f32x4*>(x + base + i * 4) - mean) * inv;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + base + i * 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 r = (g * gm - c1) * inv - xn * c2;
+    *reinterpret_cast<f32x4*>(dx + base + i * 4) = r;
+  }
+}
+
+// dgamma[c] = acc*dgamma[c] + sum_{b,split} cpart[..][0][c]; dbeta likewise with [1]
+__global__ void ln_bwd_param_kernel(const float* __restrict__ cpart, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int C, int nblk, float acc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float g = 0.f, bt = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    g += cpart[((long long)k * 2) * C + c];
+    bt += cpart[((long long)k * 2 + 1) * C + c];
+  }
+  dgamma[c] = (acc != 0.f ? acc * dgamma[c] : 0.f) + g;
+  dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + bt;
+}
+
+}  // namespace
+
+extern "C" size_t munit_instnorm_workspace_bytes(int B, int HW, int C) {
+  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256);
+}
+
+extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                                  const float* adain, int ad_ld, int w_off, int b_off, const float* residual,
+                                  int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(x && y && stats && ws, "instnorm_fwd: null pointer");
+  MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "instnorm_fwd: bad dims B=%d HW=%d C=%d", B, HW, C);
+  MUNIT_CHECK_ARG(C <= 4096, "instnorm_fwd: C=%d too large", C);
+  if (ws_bytes < munit_instnorm_workspace_bytes(B, HW, C)) {
+    munit_set_error("instnorm_fwd: workspace too small");
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pick_split(B, HW);
+  float* partial = reinterpret_cast<float*>(ws);
+  const Lay L = make_lay(C);
+  hipLaunchKernelGGL(in_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+                     partial, HW, C, ns);
+  MUNIT_CHECK_LAUNCH("in_stats");
+  hipLaunchKernelGGL(in_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, partial,
+                     stats, HW, C, ns, adain, ad_ld, w_off, b_off, residual, relu, eps);
+  MUNIT_CHECK_LAUNCH("in_apply");
+  return MUNIT_OK;
+}
+
+extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                                  int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
+                                  int relu, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(x && dy && stats && dx && ws, "instnorm_bwd: null pointer");
+  MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "instnorm_bwd: bad dims");
+  if (ws_bytes < munit_instnorm_workspace_bytes(B, HW, C)) {
+    munit_set_error("instnorm_bwd: workspace too small");
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pick_split(B, HW);
+  float* partial = reinterpret_cast<float*>(ws);
+  const Lay L = make_lay(C);
+  hipLaunchKernelGGL(in_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+                     dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
+  MUNIT_CHECK_LAUNCH("in_bwd_stats");
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, stats,
+                     partial, dx, HW, C, ns, adain, d_adain, ad_ld, w_off, b_off, relu);
+  MUNIT_CHECK_LAUNCH("in_bwd_apply");
+  return MUNIT_OK;
+}
+
+extern "C" size_t munit_layernorm_workspace_bytes(int B, int HW, int C) {
+  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256) +
+         align_up((size_t)B * MAX_SPLIT * 2 * sizeof(float), 256);
+}
+
+extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                                   const float* gamma, const float* beta, int relu, float eps, void* ws,
+                                   size_t ws_bytes, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(x && y && stats && gamma && beta && ws, "layernorm_fwd: null pointer");
+  MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm_fwd: bad dims");
+  MUNIT_CHECK_ARG((long long)HW * C > 1, "layernorm_fwd: unbiased std needs more than one element");
+  if (ws_bytes < munit_layernorm_workspace_bytes(B, HW, C)) {
+    munit_set_error("layernorm_fwd: workspace too small");
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pick_split(B, HW);
+  float* spart = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(ln_stats_kernel, dim3(ns, B), dim3(NT), 0, st, x, spart, (long long)HW * C, ns);
+  MUNIT_CHECK_LAUNCH("ln_stats");
+  hipLaunchKernelGGL(ln_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, spart, stats,
+                     HW, C, ns, gamma, beta, relu, eps);
+  MUNIT_CHECK_LAUNCH("ln_apply");
+  return MUNIT_OK;
+}
+
+extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                                   int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                   float acc, int relu, float eps, void* ws, size_t ws_bytes,
+                                   munit_stream_t stream) {
+  MUNIT_CHECK_ARG(x && dy && stats && dx && gamma && beta && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
+  MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm_bwd: bad dims");
+  if (ws_bytes < munit_layernorm_workspace_bytes(B, HW, C)) {
+    munit_set_error("layernorm_bwd: workspace too small");
+    return MUNIT_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pick_split(B, HW);
+  float* cpart = reinterpret_cast<float*>(ws);
+  float* spart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                          align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256));
+  const Lay L = make_lay(C);
+  hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+                     dy, stats, cpart, spart, HW, C, ns, gamma, beta, relu, eps);
+  MUNIT_CHECK_LAUNCH("ln_bwd_stats");
+  hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(ns, B), dim3(NT), 0, st, x, dy, stats, spart, dx, HW, C, ns, gamma,
+                     beta, relu, eps);
+  MUNIT_CHECK_LAUNCH("ln_bwd_apply");
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, cpart, dgamma, dbeta, C, B * ns,
+                     acc);
+  MUNIT_CHECK_LAUNCH("ln_bwd_param");
+  return MUNIT_OK;
+}

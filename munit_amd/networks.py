@@ -1,0 +1,528 @@
+"""MI355X-native AdaINGen / AdaINGen_double / MsImageDis.
+
+Same class names, constructor arguments, method names and state_dict key layout as the
+reference's scripts/networks.py so checkpoints and callers
+(scripts/train.py, scripts/test.py) interchange -- but nothing here calls a torch compute
+op: every layer dispatches to the HIP kernels through munit_amd.ops, activations stay NHWC
+in HBM between kernels, the upsample of the decoder is folded into the following
+convolution's gather, bias/activation ride in the conv epilogue, ReLU and the ResBlock
+residual add ride in the normalisation kernels, and the AdaIN parameters are read straight
+out of the MLP output by column offset.
+
+Parameters are ordinary nn.Parameters of the reference's shapes (OIHW) stored
+channels_last; default initialisation consumes the torch RNG exactly like nn.Conv2d /
+nn.Linear so `torch.manual_seed(s)` reproduces the reference's initial weights.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from . import ops
+
+
+# --------------------------------------------------------------------------------------
+# leaf layers
+# --------------------------------------------------------------------------------------
+class Conv2d(nn.Module):
+    """Stands in for nn.Conv2d (un-padded, networks.py:691-693 / :68 / :472).  Parameter
+    names `weight` (O, I, k, k) and `bias` (O,) as in torch."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        init.kaiming_uniform_(w, a=math.sqrt(5))  # nn.Conv2d.reset_parameters
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        if bias:
+            fan_in = in_channels * kernel_size * kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, pad, pad_type, upsample, act, slope)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size,
+                                                      self.stride)
+
+
+class Linear(nn.Module):
+    """Stands in for nn.Linear (networks.py:712)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        w = torch.empty(out_features, in_features)
+        init.kaiming_uniform_(w, a=math.sqrt(5))  # nn.Linear.reset_parameters
+        self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+            self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x, act="none"):
+        return ops.linear(x, self.weight, self.bias, act)
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False) (networks.py:657): no state."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+
+    def forward(self, x, relu=False, residual=None):
+        return ops.instance_norm(x, relu, residual, self.eps)
+
+
+class AdaptiveInstanceNorm2d(nn.Module):
+    """networks.py:810-848.  weight/bias are assigned per call by assign_adain_params; the
+    dummy running_mean / running_var buffers exist only for state_dict compatibility."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = None
+        self.bias = None
+        self._params = None  # (adain_params (B, n), weight column offset, bias column offset)
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x, relu=False, residual=None):
+        assert self.weight is not None and self.bias is not None, \
+            "Please assign weight and bias before calling AdaIN!"
+        if self._params is not None:
+            params, w_off, b_off = self._params
+        else:
+            # weight / bias assigned by hand as flat (B*C,) tensors (reference convention)
+            b, c = x.size(0), x.size(1)
+            params = torch.cat([self.bias.reshape(b, c), self.weight.reshape(b, c)], dim=1).contiguous()
+            w_off, b_off = c, 0
+        return ops.adain(x, params, w_off, b_off, relu, residual, self.eps)
+
+    def __repr__(self):
+        return self.__class__.__name__ + "(" + str(self.num_features) + ")"
+
+
+class LayerNorm(nn.Module):
+    """networks.py:851-878 (unbiased std, eps added to std, per-channel gamma/beta)."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True):
+        super().__init__()
+        self.num_features, self.affine, self.eps = num_features, affine, eps
+        if not affine:
+            raise NotImplementedError("munit_amd.LayerNorm: affine=False is not on the MUNIT hot path")
+        self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
+        self.beta = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x, relu=False):
+        return ops.layer_norm(x, self.gamma, self.beta, relu, self.eps)
+
+
+class Upsample2x(nn.Module):
+    """Placeholder keeping nn.Upsample(scale_factor=2)'s slot in Decoder.model
+    (networks.py:534); the decoder folds it into the next convolution's gather."""
+
+    def forward(self, x):
+        raise RuntimeError("Upsample2x is fused into the following Conv2dBlock; call Decoder.forward")
+
+
+class _Pad(nn.Module):
+    """Keeps the `pad` slot of Conv2dBlock (networks.py:642-649); the padding itself is index
+    arithmetic inside the convolution kernels."""
+
+    def __init__(self, kind, padding):
+        super().__init__()
+        self.kind, self.padding = kind, padding
+
+    def extra_repr(self):
+        return "%s, %d" % (self.kind, self.padding)
+
+
+# --------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------
+class Conv2dBlock(nn.Module):
+    """networks.py:627-701: activation(norm(conv(pad(x)))), bias always on."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, norm="none", activation="relu",
+                 pad_type="zero"):
+        super().__init__()
+        self.use_bias = True
+        if pad_type not in ("reflect", "zero"):
+            assert pad_type != "replicate", "munit_amd: replicate padding is not implemented (not on the hot path)"
+            assert 0, "Unsupported padding type: {}".format(pad_type)
+        self.pad = _Pad(pad_type, padding)
+        norm_dim = output_dim
+        if norm == "in":
+            self.norm = InstanceNorm2d(norm_dim)
+        elif norm == "ln":
+            self.norm = LayerNorm(norm_dim)
+        elif norm == "adain":
+            self.norm = AdaptiveInstanceNorm2d(norm_dim)
+        elif norm == "none":
+            self.norm = None
+        elif norm in ("bn", "sn"):
+            raise NotImplementedError("munit_amd: norm=%r is outside the MUNIT hot path (configs use none/in/ln/adain)"
+                                      % norm)
+        else:
+            assert 0, "Unsupported normalization: {}".format(norm)
+        if activation not in ("relu", "lrelu", "tanh", "none"):
+            if activation in ("prelu", "selu"):
+                raise NotImplementedError("munit_amd: activation=%r is not implemented" % activation)
+            assert 0, "Unsupported activation: {}".format(activation)
+        if self.norm is not None and activation not in ("relu", "none"):
+            raise NotImplementedError("munit_amd: only relu/none can follow a normalisation layer")
+        self.activation = activation
+        self.conv = Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
+
+    def forward(self, x, upsample=False, residual=None):
+        if self.norm is None:
+            y = self.conv(x, self.pad.padding, self.pad.kind, upsample, self.activation)
+            if residual is not None:
+                raise NotImplementedError("munit_amd: residual add needs a normalised block")
+            return y
+        y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none")
+        relu = self.activation == "relu"
+        if isinstance(self.norm, LayerNorm):
+            assert residual is None
+            return self.norm(y, relu)
+        return self.norm(y, relu, residual)
+
+
+class ResBlock(nn.Module):
+    """networks.py:603-624; `out += residual` is fused into the second norm kernel."""
+
+    def __init__(self, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        model = [Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation=activation, pad_type=pad_type),
+                 Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation="none", pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), residual=x)
+
+
+class ResBlocks(nn.Module):
+    """networks.py:569-580."""
+
+    def __init__(self, num_blocks, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        self.model = nn.Sequential(*[ResBlock(dim, norm=norm, activation=activation, pad_type=pad_type)
+                                     for _ in range(num_blocks)])
+
+    def forward(self, x):
+        for blk in self.model:
+            x = blk(x)
+        return x
+
+
+class LinearBlock(nn.Module):
+    """networks.py:704-749 (norm 'none' only -- what MLP uses)."""
+
+    def __init__(self, input_dim, output_dim, norm="none", activation="relu"):
+        super().__init__()
+        if norm != "none":
+            raise NotImplementedError("munit_amd.LinearBlock: norm=%r is not on the MUNIT hot path" % norm)
+        if activation not in ("relu", "lrelu", "tanh", "none"):
+            raise NotImplementedError("munit_amd.LinearBlock: activation=%r is not implemented" % activation)
+        self.fc = Linear(input_dim, output_dim, bias=True)
+        self.norm = None
+        self.activation = activation
+
+    def forward(self, x):
+        return self.fc(x, self.activation)
+
+
+class MLP(nn.Module):
+    """networks.py:583-597."""
+
+    def __init__(self, input_dim, output_dim, dim, n_blk, norm="none", activ="relu"):
+        super().__init__()
+        model = [LinearBlock(input_dim, dim, norm=norm, activation=activ)]
+        for _ in range(n_blk - 2):
+            model += [LinearBlock(dim, dim, norm=norm, activation=activ)]
+        model += [LinearBlock(dim, output_dim, norm="none", activation="none")]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        h = x.reshape(x.size(0), -1)
+        for blk in self.model:
+            h = blk(h)
+        return h
+
+
+# --------------------------------------------------------------------------------------
+# encoders / decoder
+# --------------------------------------------------------------------------------------
+class _GlobalAvgPool(nn.Module):
+    def forward(self, x):
+        return ops.global_avgpool(x)
+
+
+class StyleEncoder(nn.Module):
+    """networks.py:442-477."""
+
+    def __init__(self, n_downsample, input_dim, dim, style_dim, norm, activ, pad_type):
+        super().__init__()
+        model = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(2):
+            model += [Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+            dim *= 2
+        for _ in range(n_downsample - 2):
+            model += [Conv2dBlock(dim, dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+        model += [_GlobalAvgPool()]
+        model += [Conv2d(dim, style_dim, 1, 1)]
+        self.model = nn.Sequential(*model)
+        self.output_dim = dim
+
+    def forward(self, x):
+        for m in self.model:
+            x = m(x)
+        return x
+
+
+class ContentEncoder(nn.Module):
+    """networks.py:480-512."""
+
+    def __init__(self, n_downsample, n_res, input_dim, dim, norm, activ, pad_type):
+        super().__init__()
+        model = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(n_downsample):
+            model += [Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type)]
+            dim *= 2
+        model += [ResBlocks(n_res, dim, norm=norm, activation=activ, pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+        self.output_dim = dim
+
+    def forward(self, x):
+        for m in self.model:
+            x = m(x)
+        return x
+
+
+class Decoder(nn.Module):
+    """networks.py:515-563."""
+
+    def __init__(self, n_upsample, n_res, dim, output_dim, res_norm="adain", activ="relu", pad_type="zero"):
+        super().__init__()
+        model = [ResBlocks(n_res, dim, res_norm, activ, pad_type=pad_type)]
+        for _ in range(n_upsample):
+            model += [Upsample2x(),
+                      Conv2dBlock(dim, dim // 2, 5, 1, 2, norm="ln", activation=activ, pad_type=pad_type)]
+            dim //= 2
+        model += [Conv2dBlock(dim, output_dim, 7, 1, 3, norm="none", activation="tanh", pad_type=pad_type)]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        up = False
+        for m in self.model:
+            if isinstance(m, Upsample2x):
+                up = True
+            elif isinstance(m, Conv2dBlock):
+                x = m(x, upsample=up)
+                up = False
+            else:
+                x = m(x)
+        return x
+
+
+# --------------------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------------------
+def _assign_adain_params(adain_params, model):
+    """networks.py:230-239: AdaIN layer l (module order) takes bias = columns [2lC, 2lC+C),
+    weight = [2lC+C, 2lC+2C).  Here the slices are column offsets into the one (B, n) tensor
+    (read in place by the kernel); .weight / .bias are set to detached views so the
+    reference's 'assigned?' assertion and introspection still work."""
+    if adain_params.dim() != 2:
+        adain_params = adain_params.reshape(adain_params.size(0), -1)
+    adain_params = adain_params.contiguous()
+    off = 0
+    for m in model.modules():
+        if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
+            c = m.num_features
+            m._params = (adain_params, off + c, off)
+            m.bias = adain_params.detach()[:, off:off + c]
+            m.weight = adain_params.detach()[:, off + c:off + 2 * c]
+            if adain_params.size(1) > off + 2 * c:
+                off += 2 * c
+
+
+def _num_adain_params(model):
+    """networks.py:241-247."""
+    n = 0
+    for m in model.modules():
+        if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
+            n += 2 * m.num_features
+    return n
+
+
+class AdaINGen(nn.Module):
+    """networks.py:170-254."""
+
+    def __init__(self, input_dim, params):
+        super().__init__()
+        dim, style_dim = params["dim"], params["style_dim"]
+        n_downsample, n_res = params["n_downsample"], params["n_res"]
+        activ, pad_type, mlp_dim = params["activ"], params["pad_type"], params["mlp_dim"]
+        self.enc_style = StyleEncoder(4, input_dim, dim, style_dim, norm="none", activ=activ, pad_type=pad_type)
+        self.enc_content = ContentEncoder(n_downsample, n_res, input_dim, dim, "in", activ, pad_type=pad_type)
+        self.dec = Decoder(n_downsample, n_res, self.enc_content.output_dim, input_dim, res_norm="adain",
+                           activ=activ, pad_type=pad_type)
+        self.mlp = MLP(style_dim, self.get_num_adain_params(self.dec), mlp_dim, 3, norm="none", activ=activ)
+
+    def forward(self, images):
+        content, style_fake = self.encode(images)
+        return self.decode(content, style_fake)
+
+    def encode(self, images):
+        images = ops.nhwc(images)
+        style_fake = self.enc_style(images)
+        content = self.enc_content(images)
+        return content, style_fake
+
+    def decode(self, content, style):
+        adain_params = self.mlp(style)
+        self.assign_adain_params(adain_params, self.dec)
+        return self.dec(content)
+
+    def assign_adain_params(self, adain_params, model):
+        _assign_adain_params(adain_params, model)
+
+    def get_num_adain_params(self, model):
+        return _num_adain_params(model)
+
+    def get_adain_param(self, style):
+        return self.mlp(style)
+
+
+class AdaINGen_double(nn.Module):
+    """networks.py:262-388: one shared style encoder, two content encoders / decoders / MLPs."""
+
+    def __init__(self, input_dim, params):
+        super().__init__()
+        dim, style_dim = params["dim"], params["style_dim"]
+        n_downsample, n_res = params["n_downsample"], params["n_res"]
+        activ, pad_type, mlp_dim = params["activ"], params["pad_type"], params["mlp_dim"]
+        self.enc_style = StyleEncoder(4, input_dim, dim, style_dim, norm="none", activ=activ, pad_type=pad_type)
+        self.enc1_content = ContentEncoder(n_downsample, n_res, input_dim, dim, "in", activ, pad_type=pad_type)
+        self.enc2_content = ContentEncoder(n_downsample, n_res, input_dim, dim, "in", activ, pad_type=pad_type)
+        self.dec1 = Decoder(n_downsample, n_res, self.enc1_content.output_dim, input_dim, res_norm="adain",
+                            activ=activ, pad_type=pad_type)
+        self.dec2 = Decoder(n_downsample, n_res, self.enc2_content.output_dim, input_dim, res_norm="adain",
+                            activ=activ, pad_type=pad_type)
+        self.mlp1 = MLP(style_dim, self.get_num_adain_params(self.dec1), mlp_dim, 3, norm="none", activ=activ)
+        self.mlp2 = MLP(style_dim, self.get_num_adain_params(self.dec2), mlp_dim, 3, norm="none", activ=activ)
+
+    def forward(self, images, encoder_name):
+        content, style_fake = self.encode(images, encoder_name)
+        return self.decode(content, style_fake, encoder_name)
+
+    def encode(self, images, encoder_name):
+        images = ops.nhwc(images)
+        style_fake = self.enc_style(images)
+        if encoder_name == 1:
+            content = self.enc1_content(images)
+        elif encoder_name == 2:
+            content = self.enc2_content(images)
+        else:
+            print("wrong value for encoder_name, must be 0 or 1")
+            return None
+        return content, style_fake
+
+    def decode(self, content, style, encoder_name):
+        if encoder_name == 1:
+            adain_params = self.mlp1(style)
+            self.assign_adain_params(adain_params, self.dec1)
+            images = self.dec1(content)
+        elif encoder_name == 2:
+            adain_params = self.mlp2(style)
+            self.assign_adain_params(adain_params, self.dec2)
+            images = self.dec2(content)
+        else:
+            print("wrong value for encoder_name, must be 0 or 1")
+            return None
+        return images
+
+    def get_adain_param(self, style, encoder_name):
+        if encoder_name == 1:
+            return self.mlp1(style)
+        if encoder_name == 2:
+            return self.mlp2(style)
+        print("wrong value for encoder_name, must be 0 or 1")
+        return None
+
+    def assign_adain_params(self, adain_params, model):
+        _assign_adain_params(adain_params, model)
+
+    def get_num_adain_params(self, model):
+        return _num_adain_params(model)
+
+
+# --------------------------------------------------------------------------------------
+# discriminator
+# --------------------------------------------------------------------------------------
+class MsImageDis(nn.Module):
+    """networks.py:20-115 (LSGAN branch; nsgan hard-codes .cuda() BCE in the reference and is
+    not on the configs' path)."""
+
+    def __init__(self, input_dim, params):
+        super().__init__()
+        self.n_layer = params["n_layer"]
+        self.gan_type = params["gan_type"]
+        self.dim = params["dim"]
+        self.norm = params["norm"]
+        self.activ = params["activ"]
+        self.num_scales = params["num_scales"]
+        self.pad_type = params["pad_type"]
+        self.input_dim = input_dim
+        self.cnns = nn.ModuleList()
+        for _ in range(self.num_scales):
+            self.cnns.append(self._make_net())
+
+    def _make_net(self):
+        dim = self.dim
+        cnn_x = [Conv2dBlock(self.input_dim, dim, 4, 2, 1, norm="none", activation=self.activ,
+                             pad_type=self.pad_type)]
+        for _ in range(self.n_layer - 1):
+            cnn_x += [Conv2dBlock(dim, dim * 2, 4, 2, 1, norm=self.norm, activation=self.activ,
+                                  pad_type=self.pad_type)]
+            dim *= 2
+        cnn_x += [Conv2d(dim, 1, 1, 1)]
+        return nn.Sequential(*cnn_x)
+
+    def downsample(self, x):
+        return ops.avgpool3s2(x)
+
+    def forward(self, x):
+        x = ops.nhwc(x)
+        outputs = []
+        for i, model in enumerate(self.cnns):
+            h = x
+            for m in model:
+                h = m(h)
+            outputs.append(h)
+            if i + 1 < len(self.cnns):  # the reference also pools after the last scale and discards it
+                x = self.downsample(x)
+        return outputs
+
+    def calc_dis_loss(self, input_fake, input_real):
+        outs0 = self.forward(input_fake)
+        outs1 = self.forward(input_real)
+        assert self.gan_type == "lsgan", "Unsupported GAN type: {}".format(self.gan_type)
+        terms = []
+        for out0, out1 in zip(outs0, outs1):
+            terms += [ops.mse_const(out0, 0.0), ops.mse_const(out1, 1.0)]
+        return ops.scalar_sum(terms)
+
+    def calc_gen_loss(self, input_fake):
+        outs0 = self.forward(input_fake)
+        assert self.gan_type == "lsgan", "Unsupported GAN type: {}".format(self.gan_type)
+        return ops.scalar_sum([ops.mse_const(out0, 1.0) for out0 in outs0])

@@ -1,0 +1,482 @@
+"""torch.autograd.Function wrappers over the C ABI (include/munit_hip.h).
+
+PyTorch supplies device memory, the stream and the autograd tape; every arithmetic op of the
+hot path is a HIP kernel in libmunit_hip.so.  Tensors keep the reference's logical NCHW / OIHW
+shapes but live in channels_last memory (= NHWC / [Cout][KH][KW][Cin]), which is what the
+kernels read.  There is no CPU path: a non-HIP tensor raises.
+
+Parameter gradients: when a parameter carries a `_munit_grad` buffer (the trainer's flat
+gradient storage) backward-weight accumulates straight into it (beta = 1) and autograd gets
+None; otherwise the gradient is returned the ordinary way (used by the op-level tests).
+"""
+import ctypes
+from ctypes import byref, c_float, c_int, c_void_p
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import ACT, PAD, ConvDesc
+
+_ws_cache = {}
+# bench.py sets this to a list to time every forward-conv launch with HIP events on the launch stream:
+# entries are (kernel variant tag, algorithmic FLOPs, start event, end event).
+PROFILE = None
+
+
+def _require(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("munit_amd: %s must live on a HIP device (no CPU fallback exists); got %s"
+                           % (name, getattr(t, "device", type(t))))
+    if t.dtype != torch.float32:
+        raise RuntimeError("munit_amd: %s must be float32, got %s" % (name, t.dtype))
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _is_nhwc(t):
+    if t.dim() != 4:
+        return False
+    b, c, h, w = t.shape
+    want = (h * w * c, 1, w * c, c)
+    for size, st, ws in zip(t.shape, t.stride(), want):
+        if size > 1 and st != ws:
+            return False
+    return True
+
+
+def nhwc(t):
+    """Return t (logical NCHW) with NHWC memory; copies only when needed (layout plumbing)."""
+    if _is_nhwc(t):
+        return t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(b, c, h, w, like):
+    return torch.empty((b, c, h, w), device=like.device, dtype=torch.float32, memory_format=torch.channels_last)
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (stream-ordered reuse on the current stream)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        size = max(int(nbytes * 1.25), 1 << 20)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _desc(x, weight, stride, pad, pad_type, upsample, act="none", slope=0.2):
+    b, cin, h, w = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    if cin_w != cin:
+        raise RuntimeError("munit_amd.conv2d: weight expects %d input channels, input has %d" % (cin_w, cin))
+    return ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), ACT[act],
+                    float(slope))
+
+
+def _out_hw(d):
+    lib = _lib.load()
+    ho, wo = c_int(), c_int()
+    _lib.check(lib.munit_conv2d_out_hw(byref(d), byref(ho), byref(wo)), "conv2d_out_hw")
+    return ho.value, wo.value
+
+
+# ------------------------------------------------------------------------------------------
+# raw (non-autograd) entry points, also used by the tests
+# ------------------------------------------------------------------------------------------
+def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=0.2):
+    lib = _lib.load()
+    x, weight = nhwc(x), nhwc(weight)
+    d = _desc(x, weight, stride, pad, pad_type, upsample, act, slope)
+    ho, wo = _out_hw(d)
+    y = empty_nhwc(x.shape[0], weight.shape[0], ho, wo, x)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.munit_conv2d_fwd(byref(d), _p(x), _p(weight), _p(bias), _p(y), _stream()), "conv2d_fwd")
+    if PROFILE is not None:
+        e1.record()
+        tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if d.Cout <= 64 else 128, "true" if d.Cin % 32 == 0 else "false")
+        PROFILE.append((tag, 2.0 * d.B * ho * wo * d.Cout * d.KH * d.KW * d.Cin, e0, e1))
+    return y
+
+
+def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=None):
+    lib = _lib.load()
+    dy, weight = nhwc(dy), nhwc(weight)
+    b, cin, h, w = x_shape
+    cout, _, kh, kw = weight.shape
+    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0)
+    nbytes = lib.munit_conv2d_dgrad_workspace_bytes(byref(d))
+    ws = workspace(nbytes, dy.device)
+    dx = empty_nhwc(b, cin, h, w, dy)
+    if add is not None:
+        add = nhwc(add)
+    _lib.check(lib.munit_conv2d_dgrad(byref(d), _p(dy), _p(weight), _p(add), _p(dx), _p(ws), ws.numel(), _stream()),
+               "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=None, db=None, beta=0.0,
+                     want_bias=True):
+    """dw/db given -> accumulate (beta) in place; else fresh tensors are returned."""
+    lib = _lib.load()
+    x, dy = nhwc(x), nhwc(dy)
+    b, cin, h, w = x.shape
+    cout, _, kh, kw = weight_shape
+    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0)
+    nbytes = lib.munit_conv2d_wgrad_workspace_bytes(byref(d))
+    ws = workspace(nbytes, x.device)
+    if dw is None:
+        dw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32,
+                         memory_format=torch.channels_last)
+        beta = 0.0
+    if db is None and want_bias:
+        db = torch.empty(cout, device=x.device, dtype=torch.float32)
+    _lib.check(lib.munit_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(),
+                                      _stream()), "conv2d_wgrad")
+    return dw, db
+
+
+def act_bwd_raw(act, slope, y, dy):
+    lib = _lib.load()
+    dx = torch.empty_like(y)
+    _lib.check(lib.munit_act_bwd(ACT[act], c_float(slope), _p(y), _p(dy), _p(dx), y.numel(), _stream()), "act_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf):
+        _require(x, "conv input")
+        _require(weight, "conv weight")
+        x, w = nhwc(x), nhwc(weight)
+        y = conv2d_fwd_raw(x, w, bias, stride, pad, pad_type, upsample, act, slope)
+        ctx.cfg = (stride, pad, pad_type, upsample, act, slope)
+        ctx.has_bias = bias is not None
+        ctx.wbuf = wbuf
+        ctx.bbuf = bbuf if bias is not None else None
+        ctx.save_for_backward(x, w, y if act != "none" else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, pad_type, upsample, act, slope = ctx.cfg
+        dy = nhwc(dy)
+        if act != "none":
+            dy = act_bwd_raw(act, slope, y, dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ctx.wbuf is not None:
+                conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
+                                 want_bias=False)
+            else:
+                dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def _gbuf(p):
+    return getattr(p, "_munit_grad", None) if p is not None else None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2):
+    """pad -> conv -> bias -> activation (networks.py:695-701), optional fused nearest x2
+    upsample of the input (networks.py:534)."""
+    return _Conv2d.apply(x, weight, bias, stride, pad, pad_type, upsample, act, slope, _gbuf(weight), _gbuf(bias))
+
+
+def linear(x, weight, bias=None, act="none"):
+    """nn.Linear (+ReLU) of LinearBlock (networks.py:743-749) as a 1x1 convolution."""
+    b, k = x.shape
+    n = weight.shape[0]
+    wbuf = _gbuf(weight)
+    if wbuf is not None:
+        wbuf = wbuf.view(n, k, 1, 1)
+    y = _Conv2d.apply(x.reshape(b, k, 1, 1), weight.view(n, k, 1, 1), bias, 1, 0, "zero", False, act, 0.2, wbuf,
+                      _gbuf(bias))
+    return y.reshape(b, n)
+
+
+class _InstNorm(Function):
+    @staticmethod
+    def forward(ctx, x, adain, residual, w_off, b_off, relu, eps):
+        _require(x, "instance-norm input")
+        lib = _lib.load()
+        x = nhwc(x)
+        b, c, h, w = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((b, c, 2), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.munit_instnorm_workspace_bytes(b, h * w, c), x.device)
+        ld = 0
+        if adain is not None:
+            _require(adain, "adain params")
+            if adain.dim() != 2 or not adain.is_contiguous():
+                raise RuntimeError("munit_amd.adain: params must be a contiguous (B, n) tensor")
+            ld = adain.shape[1]
+        if residual is not None:
+            residual = nhwc(residual)
+        _lib.check(lib.munit_instnorm_fwd(_p(x), _p(y), _p(stats), b, h * w, c, _p(adain), ld, w_off, b_off,
+                                          _p(residual), int(relu), c_float(eps), _p(ws), ws.numel(), _stream()),
+                   "instnorm_fwd")
+        ctx.cfg = (w_off, b_off, relu, ld)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, stats, adain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, adain = ctx.saved_tensors
+        w_off, b_off, relu, ld = ctx.cfg
+        dy = nhwc(dy)
+        b, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        d_adain = None
+        if adain is not None and ctx.needs_input_grad[1]:
+            d_adain = torch.zeros_like(adain)
+        ws = workspace(lib.munit_instnorm_workspace_bytes(b, h * w, c), x.device)
+        _lib.check(lib.munit_instnorm_bwd(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(adain), _p(d_adain), ld,
+                                          w_off, b_off, int(relu), _p(ws), ws.numel(), _stream()), "instnorm_bwd")
+        return dx, d_adain, (dy if ctx.has_res else None), None, None, None, None
+
+
+def instance_norm(x, relu=False, residual=None, eps=1e-5):
+    """nn.InstanceNorm2d(affine=False) (networks.py:657) [+ReLU] [+residual]."""
+    return _InstNorm.apply(x, None, residual, 0, 0, relu, eps)
+
+
+def adain(x, params, w_off, b_off, relu=False, residual=None, eps=1e-5):
+    """AdaptiveInstanceNorm2d (networks.py:823-845); weight/bias are columns
+    [w_off, w_off+C) / [b_off, b_off+C) of the (B, n) MLP output."""
+    return _InstNorm.apply(x, params, residual, w_off, b_off, relu, eps)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, eps):
+        _require(x, "layer-norm input")
+        lib = _lib.load()
+        x = nhwc(x)
+        b, c, h, w = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((b, 2), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
+        _lib.check(lib.munit_layernorm_fwd(_p(x), _p(y), _p(stats), b, h * w, c, _p(gamma), _p(beta), int(relu),
+                                           c_float(eps), _p(ws), ws.numel(), _stream()), "layernorm_fwd")
+        ctx.cfg = (relu, eps)
+        ctx.gbuf = getattr(gamma, "_munit_grad", None)
+        ctx.bbuf = getattr(beta, "_munit_grad", None)
+        ctx.save_for_backward(x, stats, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, gamma, beta = ctx.saved_tensors
+        relu, eps = ctx.cfg
+        dy = nhwc(dy)
+        b, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        into = ctx.gbuf is not None and ctx.bbuf is not None
+        dgamma = ctx.gbuf if into else torch.empty_like(gamma)
+        dbeta = ctx.bbuf if into else torch.empty_like(beta)
+        ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
+        _lib.check(lib.munit_layernorm_bwd(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(gamma), _p(beta),
+                                           _p(dgamma), _p(dbeta), c_float(1.0 if into else 0.0), int(relu),
+                                           c_float(eps), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
+        if into:
+            return dx, None, None, None, None
+        return dx, dgamma, dbeta, None, None
+
+
+def layer_norm(x, gamma, beta, relu=False, eps=1e-5):
+    """MUNIT's LayerNorm (networks.py:862-878) [+ReLU]."""
+    return _LayerNorm.apply(x, gamma, beta, relu, eps)
+
+
+class _AvgPool3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "avgpool input")
+        lib = _lib.load()
+        x = nhwc(x)
+        b, c, h, w = x.shape
+        y = empty_nhwc(b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x)
+        _lib.check(lib.munit_avgpool3s2_fwd(_p(x), _p(y), b, h, w, c, _stream()), "avgpool_fwd")
+        ctx.shape = (b, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        b, c, h, w = ctx.shape
+        dy = nhwc(dy)
+        dx = empty_nhwc(b, c, h, w, dy)
+        _lib.check(lib.munit_avgpool3s2_bwd(_p(dy), _p(dx), b, h, w, c, _stream()), "avgpool_bwd")
+        return dx
+
+
+def avgpool3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False) (networks.py:32-34)."""
+    return _AvgPool3s2.apply(x)
+
+
+class _GlobalAvgPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "global-avgpool input")
+        lib = _lib.load()
+        x = nhwc(x)
+        b, c, h, w = x.shape
+        y = empty_nhwc(b, c, 1, 1, x)
+        _lib.check(lib.munit_gap_fwd(_p(x), _p(y), b, h * w, c, _stream()), "gap_fwd")
+        ctx.shape = (b, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        b, c, h, w = ctx.shape
+        dy = dy.contiguous()
+        dx = empty_nhwc(b, c, h, w, dy)
+        _lib.check(lib.munit_gap_bwd(_p(dy), _p(dx), b, h * w, c, _stream()), "gap_bwd")
+        return dx
+
+
+def global_avgpool(x):
+    """nn.AdaptiveAvgPool2d(1) (networks.py:471)."""
+    return _GlobalAvgPool.apply(x)
+
+
+class _L1Mean(Function):
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        _require(a, "l1 input")
+        _require(b, "l1 target")
+        lib = _lib.load()
+        if a.shape != b.shape:
+            raise RuntimeError("munit_amd.l1_mean: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        if a.dim() == 4:
+            a, b = nhwc(a), nhwc(b)
+            c = a.shape[1]
+        else:
+            a, b = a.contiguous(), b.contiguous()
+            c = 1
+        npix = a.numel() // c
+        if mask is not None:
+            _require(mask, "l1 mask")
+            mask = mask.contiguous()
+            if mask.numel() != npix:
+                raise RuntimeError("munit_amd.l1_mean: mask must have one value per pixel (B,1,H,W)")
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = workspace(lib.munit_loss_workspace_bytes(a.numel()), a.device)
+        _lib.check(lib.munit_l1_mean_fwd(_p(a), _p(b), _p(mask), npix, c, _p(out), _p(ws), ws.numel(), _stream()),
+                   "l1_mean_fwd")
+        ctx.c = c
+        ctx.save_for_backward(a, b, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        a, b, mask = ctx.saved_tensors
+        gout = gout.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.munit_l1_mean_bwd(_p(a), _p(b), _p(mask), a.numel() // ctx.c, ctx.c, _p(gout), _p(da), _p(db),
+                                         _stream()), "l1_mean_bwd")
+        return da, db, None
+
+
+def l1_mean(a, b, mask=None):
+    """recon_criterion / recon_criterion_mask (trainer.py:279-305)."""
+    return _L1Mean.apply(a, b, mask)
+
+
+class _MseConst(Function):
+    @staticmethod
+    def forward(ctx, x, target):
+        _require(x, "mse input")
+        lib = _lib.load()
+        x = nhwc(x) if x.dim() == 4 else x.contiguous()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = workspace(lib.munit_loss_workspace_bytes(x.numel()), x.device)
+        _lib.check(lib.munit_mse_const_fwd(_p(x), c_float(target), x.numel(), _p(out), _p(ws), ws.numel(), _stream()),
+                   "mse_const_fwd")
+        ctx.target = target
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        _lib.check(lib.munit_mse_const_bwd(_p(x), c_float(ctx.target), x.numel(), _p(gout.contiguous()), _p(dx),
+                                           _stream()), "mse_const_bwd")
+        return dx, None
+
+
+def mse_const(x, target):
+    """LSGAN term torch.mean((x - target) ** 2) (networks.py:91,109)."""
+    return _MseConst.apply(x, float(target))
+
+
+class _ScalarSum(Function):
+    """sum of device scalars with unit weights; backward hands the upstream gradient to every
+    term unchanged (no kernel)."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        ctx.n = len(terms)
+        return weighted_sum(terms, [1.0] * len(terms))
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (gout,) * ctx.n
+
+
+def scalar_sum(terms):
+    return _ScalarSum.apply(*terms)
+
+
+def weighted_sum(terms, weights):
+    """Device-side sum_i w_i * term_i of scalar tensors (no autograd; logging value of the
+    total loss, trainer.py:539-558 / 1181-1184)."""
+    lib = _lib.load()
+    n = len(terms)
+    out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+    ptrs = (c_void_p * n)(*[t.data_ptr() for t in terms])
+    ws_ = (c_float * n)(*[float(w) for w in weights])
+    _lib.check(lib.munit_weighted_sum(ptrs, ws_, n, _p(out), _stream()), "weighted_sum")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    lib = _lib.load()
+    for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+        _require(t, "adam " + nm)
+    _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), c_float(lr), c_float(beta1),
+                                   c_float(beta2), c_float(eps), c_float(weight_decay), int(step), _stream()),
+               "adam_step")
+
+
+def scale_(x, alpha):
+    lib = _lib.load()
+    _require(x, "scale input")
+    _lib.check(lib.munit_scale(_p(x), _p(x), x.numel(), c_float(alpha), 0, _stream()), "scale")
+    return x

@@ -1,0 +1,458 @@
+"""MUNIT_Trainer: drop-in for the reference's scripts/trainer.py hot path on MI355X.
+
+Same constructor / gen_update / dis_update / update_learning_rate / forward / sample / save /
+resume surface and `self.loss_*` attribute names, so scripts/train.py
+can swap `from trainer import MUNIT_Trainer` for `from munit_amd.trainer import MUNIT_Trainer`.
+
+What is different underneath (none of it changes results beyond fp32 rounding):
+  * every layer runs as a HIP kernel (munit_amd.ops); nothing falls back to torch ops;
+  * generator and discriminator parameters, their gradients and the Adam moments live in flat
+    fp32 buffers: backward-weight accumulates straight into the flat gradient, Adam is one
+    fused kernel per optimizer, and data-parallel training is ONE all-reduce per update over
+    RCCL/xGMI (torch.distributed backend "nccl") of that flat buffer -- 109 MB (G) / 66 MB (D);
+  * work the reference does and then throws away is skipped: D weight-gradients inside
+    gen_update (zeroed by dis_update, trainer.py:1145), the autograd graph of the generator
+    inside dis_update (x_ba / x_ab are detached at trainer.py:1178-1179);
+  * loss scalars stay on the device; nothing synchronises the host inside an update.
+
+Aux losses outside the AdaINGen + MsImageDis path (VGG, semantic segmentation, domain
+classifiers, synthetic pairs) raise NotImplementedError when their weight is non-zero.
+"""
+import os
+import warnings
+
+import torch
+import torch.nn as nn
+from torch.optim import Optimizer
+
+from . import ops
+from .networks import AdaINGen, AdaINGen_double, InstanceNorm2d, MsImageDis
+from .utils import get_model_list, get_scheduler, normalize_config, weights_init
+
+
+class FusedAdam(Optimizer):
+    """torch.optim.Adam semantics (L2-coupled weight decay, amsgrad off; trainer.py:109-120)
+    executed as one HIP kernel over a flat parameter buffer.  state_dict()/load_state_dict()
+    speak torch.optim.Adam's format so `optimizer.pt` files interchange with the reference."""
+
+    def __init__(self, params, lr, betas, weight_decay, eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._plist = [p for g in self.param_groups for p in g["params"]]
+        self._step = 0
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self._views = None
+
+    # ---- flat storage -----------------------------------------------------------------
+    @staticmethod
+    def _view(flat, off, p):
+        n = p.numel()
+        v = flat[off:off + n]
+        if p.dim() == 4:
+            o, i, kh, kw = p.shape
+            return v.view(o, kh, kw, i).permute(0, 3, 1, 2)  # logical OIHW, memory [O][KH][KW][I]
+        return v.view(p.shape)
+
+    def bind(self, device):
+        """(Re)build the flat buffers on `device`, re-pointing every parameter at its slice."""
+        offs, total = [], 0
+        for p in self._plist:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        flat_p = torch.zeros(total, dtype=torch.float32, device=device)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=device)
+        flat_m = torch.zeros(total, dtype=torch.float32, device=device)
+        flat_v = torch.zeros(total, dtype=torch.float32, device=device)
+        if self.flat_m is not None and self.flat_m.numel() == total:
+            flat_m.copy_(self.flat_m)
+            flat_v.copy_(self.flat_v)
+        views = []
+        with torch.no_grad():
+            for p, off in zip(self._plist, offs):
+                if p.dtype != torch.float32:
+                    raise RuntimeError("munit_amd: parameters must stay float32")
+                pv = self._view(flat_p, off, p)
+                pv.copy_(p.data)
+                p.data = pv
+                gv = self._view(flat_g, off, p)
+                p._munit_grad = gv
+                p.grad = gv
+                views.append((self._view(flat_m, off, p), self._view(flat_v, off, p)))
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v = flat_p, flat_g, flat_m, flat_v
+        self._views = views
+
+    # ---- optimizer API ----------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._step += 1
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
+                      g["eps"], g["weight_decay"], self._step)
+
+    def state_dict(self):
+        state = {}
+        for i, (m, v) in enumerate(self._views):
+            state[i] = {"step": torch.tensor(float(self._step)),
+                        "exp_avg": m.detach().clone(memory_format=torch.contiguous_format),
+                        "exp_avg_sq": v.detach().clone(memory_format=torch.contiguous_format)}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(len(g["params"])))
+            groups.append(d)
+        return {"state": state if self._step > 0 else {}, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        with torch.no_grad():
+            for i, (m, v) in enumerate(self._views):
+                if i in st:
+                    m.copy_(st[i]["exp_avg"])
+                    v.copy_(st[i]["exp_avg_sq"])
+                    self._step = int(float(st[i]["step"]))
+        for g, lg in zip(self.param_groups, sd["param_groups"]):
+            for k, val in lg.items():
+                if k != "params":
+                    g[k] = val
+
+
+class MUNIT_Trainer(nn.Module):
+    def __init__(self, hyperparameters):
+        super(MUNIT_Trainer, self).__init__()
+        hyperparameters = normalize_config(hyperparameters)
+        lr = hyperparameters["lr"]
+        self.gen_state = hyperparameters["gen_state"]
+        self.guided = hyperparameters["guided"]
+        self.newsize = hyperparameters["crop_image_height"]
+        self.semantic_w = hyperparameters["semantic_w"] > 0
+        self.recon_mask = hyperparameters["recon_mask"] == 1
+        self.dann_scheduler = None
+        self.full_adaptation = hyperparameters["adaptation"]["full_adaptation"] == 1
+        self.hyperparameters = hyperparameters
+        self.iterations = 0
+
+        if "extra" in hyperparameters["optimizer"]:
+            raise NotImplementedError("munit_amd: ExtraAdam (scripts/extraadam.py) is a later scope row "
+                                      "(SURVEY.md section 8f #1); use optimizer: adam")
+        self.domain_classif_ab = hyperparameters.get("domain_adv_w", 0) > 0
+        self.use_classifier_sr = hyperparameters["adaptation"]["dfeat_lambda"] > 0
+        self.train_seg = hyperparameters["adaptation"]["sem_seg_lambda"] > 0
+        self.use_output_classifier_sr = hyperparameters["adaptation"]["output_classifier_lambda"] > 0
+        self._check_aux(hyperparameters)
+
+        if self.gen_state == 0:
+            self.gen_a = AdaINGen(hyperparameters["input_dim_a"], hyperparameters["gen"])
+            self.gen_b = AdaINGen(hyperparameters["input_dim_b"], hyperparameters["gen"])
+        elif self.gen_state == 1:
+            self.gen = AdaINGen_double(hyperparameters["input_dim_a"], hyperparameters["gen"])
+        else:
+            raise ValueError("self.gen_state unknown value: %r" % (self.gen_state,))
+        self.dis_a = MsImageDis(hyperparameters["input_dim_a"], hyperparameters["dis"])
+        self.dis_b = MsImageDis(hyperparameters["input_dim_b"], hyperparameters["dis"])
+        self.instancenorm = InstanceNorm2d(512)
+        self.style_dim = hyperparameters["gen"]["style_dim"]
+
+        # fixed display noise (trainer.py:93-95); kept on the host until a device is known
+        display_size = int(hyperparameters["display_size"])
+        self.s_a = torch.randn(display_size, self.style_dim, 1, 1)
+        self.s_b = torch.randn(display_size, self.style_dim, 1, 1)
+
+        beta1, beta2 = hyperparameters["beta1"], hyperparameters["beta2"]
+        dis_params = list(self.dis_a.parameters()) + list(self.dis_b.parameters())
+        if self.gen_state == 0:
+            gen_params = list(self.gen_a.parameters()) + list(self.gen_b.parameters())
+        else:
+            gen_params = list(self.gen.parameters())
+        self.dis_opt = FusedAdam([p for p in dis_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
+                                 weight_decay=hyperparameters["weight_decay"])
+        self.gen_opt = FusedAdam([p for p in gen_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
+                                 weight_decay=hyperparameters["weight_decay"])
+        self.dis_scheduler = get_scheduler(self.dis_opt, hyperparameters)
+        self.gen_scheduler = get_scheduler(self.gen_opt, hyperparameters)
+
+        # Network weight initialization (trainer.py:124-127)
+        self.apply(weights_init(hyperparameters["init"]))
+        self.dis_a.apply(weights_init("gaussian"))
+        self.dis_b.apply(weights_init("gaussian"))
+
+        self._consts = {}
+        self._bind(torch.device("cpu"))
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_aux(hp):
+        bad = []
+        if hp.get("vgg_w", 0) > 0:
+            bad.append("vgg_w")
+        if hp.get("semantic_w", 0) > 0:
+            bad.append("semantic_w")
+        if hp.get("domain_adv_w", 0) > 0:
+            bad.append("domain_adv_w")
+        for k in ("adv_lambda", "dfeat_lambda", "sem_seg_lambda", "output_classifier_lambda", "output_adv_lambda"):
+            if hp["adaptation"].get(k, 0) > 0:
+                bad.append("adaptation." + k)
+        if bad:
+            raise NotImplementedError(
+                "munit_amd covers the AdaINGen + MsImageDis training step only; set these weights to 0 "
+                "(they need external checkpoints / models outside the hot path): " + ", ".join(bad))
+
+    def _bind(self, device):
+        self.dis_opt.bind(device)
+        self.gen_opt.bind(device)
+        self._consts = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        p = next(self.dis_a.parameters())
+        self._bind(p.device)
+        self.s_a = self.s_a.to(p.device)
+        self.s_b = self.s_b.to(p.device)
+        return out
+
+    def _const(self, value, device):
+        key = (float(value), device)
+        t = self._consts.get(key)
+        if t is None:
+            t = torch.full((), float(value), dtype=torch.float32, device=device)
+            self._consts[key] = t
+        return t
+
+    # ---- optimizer steps (trainer.py:252-268) -----------------------------------------
+    def dis_opt_step(self):
+        self.dis_opt.step()
+
+    def gen_opt_step(self):
+        self.gen_opt.step()
+
+    # ---- criteria (trainer.py:279-305) ------------------------------------------------
+    def recon_criterion(self, input, target):
+        return ops.l1_mean(input, target)
+
+    def recon_criterion_mask(self, input, target, mask):
+        return ops.l1_mean(input, target, mask)
+
+    # ---- generator dispatch -----------------------------------------------------------
+    def _enc(self, x, k):
+        if self.gen_state == 1:
+            return self.gen.encode(x, k)
+        return (self.gen_a if k == 1 else self.gen_b).encode(x)
+
+    def _dec(self, c, s, k):
+        if self.gen_state == 1:
+            return self.gen.decode(c, s, k)
+        return (self.gen_a if k == 1 else self.gen_b).decode(c, s)
+
+    def forward(self, x_a, x_b):
+        """trainer.py:307-334."""
+        self.eval()
+        with torch.no_grad():
+            s_a, s_b = self.s_a.to(x_a.device), self.s_b.to(x_a.device)
+            c_a, _ = self._enc(x_a, 1)
+            c_b, _ = self._enc(x_b, 2)
+            x_ba = self._dec(c_b, s_a, 1)
+            x_ab = self._dec(c_a, s_b, 2)
+        self.train()
+        return x_ab, x_ba
+
+    @staticmethod
+    def _all_reduce_mean(flat):
+        """Data-parallel exchange: one all-reduce (RCCL over xGMI) of the flat gradient."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(flat)
+            if flat.is_cuda:
+                ops.scale_(flat, 1.0 / dist.get_world_size())
+            else:
+                flat.mul_(1.0 / dist.get_world_size())
+
+    # ---- gen_update (trainer.py:336-561) -----------------------------------------------
+    def gen_update(self, x_a, x_b, hyperparameters, mask_a=None, mask_b=None, comet_exp=None, synth=False,
+                   semantic_gt_a=None, semantic_gt_b=None):
+        hp = hyperparameters
+        if synth and hp.get("recon_synth_w", 0) > 0:
+            raise NotImplementedError("munit_amd: synthetic-pair reconstruction loss is outside the hot path")
+        self._check_aux(normalize_config(hp))
+        self.gen_opt.zero_grad()
+        # the reference draws these even when guided == 1 leaves them unused (trainer.py:366-367)
+        s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
+        s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
+        dev = x_a.device
+        x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
+
+        d_params = list(self.dis_a.parameters()) + list(self.dis_b.parameters())
+        for p in d_params:  # D weight gradients made here would be discarded (trainer.py:1145)
+            p.requires_grad_(False)
+        try:
+            c_a, s_a_prime = self._enc(x_a, 1)
+            c_b, s_b_prime = self._enc(x_b, 2)
+            x_a_recon = self._dec(c_a, s_a_prime, 1)
+            x_b_recon = self._dec(c_b, s_b_prime, 2)
+            if self.guided == 0:
+                s_a_use, s_b_use = s_a.to(dev), s_b.to(dev)
+            elif self.guided == 1:
+                s_a_use, s_b_use = s_a_prime, s_b_prime
+            else:
+                raise ValueError("self.guided unknown value: %r" % (self.guided,))
+            x_ba = self._dec(c_b, s_a_use, 1)
+            x_ab = self._dec(c_a, s_b_use, 2)
+            c_b_recon, s_a_recon = self._enc(x_ba, 1)
+            c_a_recon, s_b_recon = self._enc(x_ab, 2)
+            cyc = hp["recon_x_cyc_w"] > 0
+            x_aba = self._dec(c_a_recon, s_a_prime, 1) if cyc else None
+            x_bab = self._dec(c_b_recon, s_b_prime, 2) if cyc else None
+
+            self.loss_gen_recon_x_a = self.recon_criterion(x_a_recon, x_a)
+            self.loss_gen_recon_x_b = self.recon_criterion(x_b_recon, x_b)
+            self.loss_gen_recon_s_a = self.recon_criterion(s_a_recon, s_a_use)
+            self.loss_gen_recon_s_b = self.recon_criterion(s_b_recon, s_b_use)
+            self.loss_gen_recon_c_a = self.recon_criterion(c_a_recon, c_a)
+            self.loss_gen_recon_c_b = self.recon_criterion(c_b_recon, c_b)
+            self.loss_gen_recon_synth = 0
+            if cyc:
+                if self.recon_mask:
+                    if mask_a is None or mask_b is None:
+                        raise ValueError("recon_mask == 1 needs mask_a and mask_b of shape (B,1,H,W)")
+                    self.loss_gen_cycrecon_x_a = self.recon_criterion_mask(x_aba, x_a, mask_a)
+                    self.loss_gen_cycrecon_x_b = self.recon_criterion_mask(x_bab, x_b, mask_b)
+                else:
+                    self.loss_gen_cycrecon_x_a = self.recon_criterion(x_aba, x_a)
+                    self.loss_gen_cycrecon_x_b = self.recon_criterion(x_bab, x_b)
+            else:
+                self.loss_gen_cycrecon_x_a = 0
+                self.loss_gen_cycrecon_x_b = 0
+            self.loss_gen_adv_a = self.dis_a.calc_gen_loss(x_ba)
+            self.loss_gen_adv_b = self.dis_b.calc_gen_loss(x_ab)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        self.loss_gen_vgg_a = self.loss_gen_vgg_b = 0
+        self.loss_sem_seg = self.domain_adv_loss = self.loss_classifier_sr = self.loss_output_classifier_sr = 0
+
+        pairs = [(hp["gan_w"], self.loss_gen_adv_a), (hp["gan_w"], self.loss_gen_adv_b),
+                 (hp["recon_x_w"], self.loss_gen_recon_x_a), (hp["recon_s_w"], self.loss_gen_recon_s_a),
+                 (hp["recon_c_w"], self.loss_gen_recon_c_a), (hp["recon_x_w"], self.loss_gen_recon_x_b),
+                 (hp["recon_s_w"], self.loss_gen_recon_s_b), (hp["recon_c_w"], self.loss_gen_recon_c_b)]
+        if cyc:
+            pairs += [(hp["recon_x_cyc_w"], self.loss_gen_cycrecon_x_a),
+                      (hp["recon_x_cyc_w"], self.loss_gen_cycrecon_x_b)]
+        self.loss_gen_total = ops.weighted_sum([t.detach() for _, t in pairs], [w for w, _ in pairs])
+        live = [(w, t) for w, t in pairs if w != 0 and t.requires_grad]
+        torch.autograd.backward([t for _, t in live], [self._const(w, dev) for w, _ in live])
+        self._all_reduce_mean(self.gen_opt.flat_g)
+        self.gen_opt_step()
+        self._log(comet_exp, ("loss_gen_adv_a", "loss_gen_adv_b", "loss_gen_recon_x_a", "loss_gen_recon_s_a",
+                              "loss_gen_recon_c_a", "loss_gen_recon_x_b", "loss_gen_recon_s_b",
+                              "loss_gen_recon_c_b", "loss_gen_cycrecon_x_a", "loss_gen_cycrecon_x_b",
+                              "loss_gen_total"))
+
+    # ---- dis_update (trainer.py:1133-1190) ---------------------------------------------
+    def dis_update(self, x_a, x_b, hyperparameters, comet_exp=None):
+        hp = hyperparameters
+        self.dis_opt.zero_grad()
+        s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
+        s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
+        dev = x_a.device
+        x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
+        with torch.no_grad():  # the generator graph would never be back-propagated here
+            c_a, s_a_prime = self._enc(x_a, 1)
+            c_b, s_b_prime = self._enc(x_b, 2)
+            if self.guided == 0:
+                x_ba = self._dec(c_b, s_a.to(dev), 1)
+                x_ab = self._dec(c_a, s_b.to(dev), 2)
+            elif self.guided == 1:
+                x_ba = self._dec(c_b, s_a_prime, 1)
+                x_ab = self._dec(c_a, s_b_prime, 2)
+            else:
+                raise ValueError("self.guided unknown value: %r" % (self.guided,))
+        self.loss_dis_a = self.dis_a.calc_dis_loss(x_ba.detach(), x_a)
+        self.loss_dis_b = self.dis_b.calc_dis_loss(x_ab.detach(), x_b)
+        self.loss_dis_total = ops.weighted_sum([self.loss_dis_a.detach(), self.loss_dis_b.detach()],
+                                               [hp["gan_w"], hp["gan_w"]])
+        w = self._const(hp["gan_w"], dev)
+        torch.autograd.backward([self.loss_dis_a, self.loss_dis_b], [w, w])
+        self._all_reduce_mean(self.dis_opt.flat_g)
+        self.dis_opt_step()
+        self._log(comet_exp, ("loss_dis_b", "loss_dis_a"))
+
+    def _log(self, comet_exp, names):
+        if comet_exp is not None and self.iterations % 100 == 0:
+            for n in names:
+                v = getattr(self, n)
+                comet_exp.log_metric(n, v.cpu().detach() if torch.is_tensor(v) else v)
+
+    # ---- schedule (trainer.py:1326-1335) ------------------------------------------------
+    def update_learning_rate(self):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # scheduler-before-optimizer order is the reference's (train.py:172)
+            if self.dis_scheduler is not None:
+                self.dis_scheduler.step()
+            if self.gen_scheduler is not None:
+                self.gen_scheduler.step()
+
+    # ---- sampling (trainer.py:773-928, core outputs only) -------------------------------
+    def sample(self, x_a, x_b):
+        self.eval()
+        outs = [[] for _ in range(6)]
+        with torch.no_grad():
+            s_a1, s_b1 = self.s_a.to(x_a.device), self.s_b.to(x_a.device)
+            s_a2 = torch.randn(x_a.size(0), self.style_dim, 1, 1).to(x_a.device)
+            s_b2 = torch.randn(x_b.size(0), self.style_dim, 1, 1).to(x_a.device)
+            for i in range(x_a.size(0)):
+                xa, xb = x_a[i:i + 1], x_b[i:i + 1]
+                c_a, s_a_fake = self._enc(xa, 1)
+                c_b, s_b_fake = self._enc(xb, 2)
+                outs[0].append(self._dec(c_a, s_a_fake, 1))
+                outs[1].append(self._dec(c_b, s_b_fake, 2))
+                if self.guided == 0:
+                    outs[2].append(self._dec(c_b, s_a1[i:i + 1], 1))
+                    outs[3].append(self._dec(c_b, s_a2[i:i + 1], 1))
+                    outs[4].append(self._dec(c_a, s_b1[i:i + 1], 2))
+                    outs[5].append(self._dec(c_a, s_b2[i:i + 1], 2))
+                else:
+                    outs[2].append(self._dec(c_b, s_a_fake, 1))
+                    outs[3].append(self._dec(c_b, s_a_fake, 1))
+                    outs[4].append(self._dec(c_a, s_b_fake, 2))
+                    outs[5].append(self._dec(c_a, s_b_fake, 2))
+        x_a_recon, x_b_recon, x_ba1, x_ba2, x_ab1, x_ab2 = (torch.cat(o) for o in outs)
+        self.train()
+        return x_a, x_a_recon, x_ab1, x_ab2, x_b, x_b_recon, x_ba1, x_ba2
+
+    # ---- checkpoints (trainer.py:1337-1429) ---------------------------------------------
+    @staticmethod
+    def _plain(sd):
+        return {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in sd.items()}
+
+    def save(self, snapshot_dir, iterations):
+        gen_name = os.path.join(snapshot_dir, "gen_%08d.pt" % (iterations + 1))
+        dis_name = os.path.join(snapshot_dir, "dis_%08d.pt" % (iterations + 1))
+        opt_name = os.path.join(snapshot_dir, "optimizer.pt")
+        if self.gen_state == 0:
+            torch.save({"a": self._plain(self.gen_a.state_dict()), "b": self._plain(self.gen_b.state_dict())},
+                       gen_name)
+        else:
+            torch.save({"2": self._plain(self.gen.state_dict())}, gen_name)
+        torch.save({"a": self._plain(self.dis_a.state_dict()), "b": self._plain(self.dis_b.state_dict())}, dis_name)
+        torch.save({"gen": self.gen_opt.state_dict(), "dis": self.dis_opt.state_dict()}, opt_name)
+
+    def resume(self, checkpoint_dir, hyperparameters):
+        last_model_name = get_model_list(checkpoint_dir, "gen")
+        state_dict = torch.load(last_model_name, map_location="cpu", weights_only=True)
+        if self.gen_state == 0:
+            self.gen_a.load_state_dict(state_dict["a"])
+            self.gen_b.load_state_dict(state_dict["b"])
+        else:
+            self.gen.load_state_dict(state_dict["2"])
+        iterations = int(last_model_name[-11:-3])
+        last_model_name = get_model_list(checkpoint_dir, "dis")
+        state_dict = torch.load(last_model_name, map_location="cpu", weights_only=True)
+        self.dis_a.load_state_dict(state_dict["a"])
+        self.dis_b.load_state_dict(state_dict["b"])
+        state_dict = torch.load(os.path.join(checkpoint_dir, "optimizer.pt"), map_location="cpu", weights_only=True)
+        self.dis_opt.load_state_dict(state_dict["dis"])
+        self.gen_opt.load_state_dict(state_dict["gen"])
+        self.dis_scheduler = get_scheduler(self.dis_opt, hyperparameters, iterations)
+        self.gen_scheduler = get_scheduler(self.gen_opt, hyperparameters, iterations)
+        print("Resume from iteration %d" % iterations)
+        return iterations

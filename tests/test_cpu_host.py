@@ -1,0 +1,206 @@
+"""CPU (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirror of the reference interface (module tree, state_dict keys, init RNG stream, config
+defaults, LR schedule, optimizer state format) and the data-parallel exchange over gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import munit_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+def test_library_exports_every_declared_symbol(built):
+    from munit_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "munit_hip.h")).read()
+    declared = set(re.findall(r"\b(munit_[a-z0-9_]+)\s*\(", header))
+    declared -= {"munit_stream_t"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.munit_version() >= 1
+
+
+def test_host_arg_checks_without_gpu(built):
+    """Argument validation happens on the host before any launch."""
+    from ctypes import byref, c_int
+    from munit_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc(1, 4, 4, 8, 8, 3, 3, 1, 4, 1, 0, 0, 0.0)  # reflect pad 4 >= H
+    ho, wo = c_int(), c_int()
+    assert lib.munit_conv2d_out_hw(byref(d), byref(ho), byref(wo)) != 0
+    assert b"reflect" in lib.munit_last_error()
+    d = _lib.ConvDesc(2, 16, 16, 64, 128, 4, 4, 2, 1, 1, 0, 0, 0.0)
+    assert lib.munit_conv2d_out_hw(byref(d), byref(ho), byref(wo)) == 0 and (ho.value, wo.value) == (8, 8)
+    d = _lib.ConvDesc(2, 16, 16, 256, 128, 5, 5, 1, 2, 1, 1, 0, 0.0)
+    assert lib.munit_conv2d_out_hw(byref(d), byref(ho), byref(wo)) == 0 and (ho.value, wo.value) == (32, 32)
+    assert lib.munit_conv2d_dgrad_workspace_bytes(byref(d)) > 0
+    assert lib.munit_conv2d_wgrad_workspace_bytes(byref(d)) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from munit_amd import ops
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.instance_norm(torch.zeros(1, 4, 4, 4))
+
+
+@pytest.mark.parametrize("gs", [1, 0])
+def test_state_dict_layout_and_init_stream_match_reference(golden, gs):
+    """Same seed -> same module tree, key order and initial weights as the reference's
+    construction sequence (trainer.py:67-127 driven over the reference modules in
+    make_golden.py)."""
+    from munit_amd.trainer import MUNIT_Trainer
+    meta, _ = golden
+    g = meta["init_gs%d" % gs]
+    hp = O.default_hp(64, 1, gs)
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(hp)
+    assert [k for k, _ in tr.named_parameters()] == g["keys"]
+    assert list(tr.state_dict().keys()) == g["state_keys"]
+
+    def dg(t):
+        f = t.detach().double().reshape(-1)
+        idx = torch.linspace(0, f.numel() - 1, 8).long()
+        return [float(f.sum()), float(f.abs().sum()), float(f.norm())] + [float(v) for v in f[idx]]
+
+    for (k, p), d in zip(tr.named_parameters(), g["digests"]):
+        got = dg(p)
+        assert max(abs(a - b) for a, b in zip(got, d)) <= 1e-6 * max(1.0, abs(d[1])), k
+    assert max(abs(a - b) for a, b in zip(dg(tr.s_a), g["s_a"])) < 1e-6
+    assert max(abs(a - b) for a, b in zip(dg(tr.s_b), g["s_b"])) < 1e-6
+
+
+def test_param_counts_and_flat_buffers():
+    from munit_amd.trainer import MUNIT_Trainer
+    tr = MUNIT_Trainer(O.default_hp(64, 1, 1))
+    assert sum(p.numel() for p in tr.gen.parameters()) == 27293590
+    assert sum(p.numel() for p in tr.dis_a.parameters()) == 8271171
+    # every parameter is a view into the optimizer's flat buffer, conv weights stored [O][KH][KW][I]
+    w = tr.gen.enc_style.model[1].conv.weight
+    assert w.shape == (128, 64, 4, 4) and w.stride() == (1024, 1, 256, 64)
+    lo, hi = tr.gen_opt.flat_p.data_ptr(), tr.gen_opt.flat_p.data_ptr() + 4 * tr.gen_opt.flat_p.numel()
+    for p in tr.gen.parameters():
+        assert lo <= p.data_ptr() < hi and p.data_ptr() % 16 == 0
+        assert p._munit_grad.shape == p.shape and p.grad is p._munit_grad
+    tr2 = MUNIT_Trainer(O.default_hp(64, 1, 0))
+    assert sum(p.numel() for p in tr2.gen_a.parameters()) == 15030291
+
+
+def test_config_defaults_and_unsupported_losses(tmp_path):
+    from munit_amd import get_config
+    from munit_amd.trainer import MUNIT_Trainer
+    import yaml
+    hp = O.default_hp(64, 1, 1)
+    del hp["adaptation"], hp["optimizer"]          # a stale config like config_HD.yaml
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(hp))
+    conf = get_config(str(p))
+    assert conf["optimizer"] == "adam" and conf["adaptation"]["adv_lambda"] == 0
+    MUNIT_Trainer(conf)
+    bad = O.default_hp(64, 1, 1)
+    bad["semantic_w"] = 3
+    with pytest.raises(NotImplementedError, match="semantic_w"):
+        MUNIT_Trainer(bad)
+    bad = O.default_hp(64, 1, 1)
+    bad["optimizer"] = "extraadam"
+    with pytest.raises(NotImplementedError):
+        MUNIT_Trainer(bad)
+
+
+def test_lr_schedule_matches_reference_order():
+    """scheduler stepped at the start of each iteration (train.py:172); StepLR(step_size, gamma)."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(64, 1, 1)
+    hp["step_size"] = 2
+    tr = MUNIT_Trainer(hp)
+    lrs = []
+    for _ in range(5):
+        tr.update_learning_rate()
+        lrs.append(tr.gen_opt.param_groups[0]["lr"])
+    assert lrs == [O.step_lr(hp["lr"], n, hp) for n in range(1, 6)]
+    assert tr.dis_opt.param_groups[0]["lr"] == lrs[-1]
+
+
+def test_optimizer_state_dict_is_torch_adam_format():
+    from munit_amd.trainer import MUNIT_Trainer
+    tr = MUNIT_Trainer(O.default_hp(64, 1, 1))
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone(memory_format=torch.contiguous_format))
+                            for p in tr.dis_opt._plist], lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-4)
+    for p in ref.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    mine = tr.dis_opt
+    mine.load_state_dict(ref.state_dict())
+    assert mine._step == 1
+    sd = mine.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(mine._plist)
+    for i, st in ref.state_dict()["state"].items():
+        assert torch.equal(sd["state"][i]["exp_avg"], st["exp_avg"])
+        assert sd["state"][i]["exp_avg"].is_contiguous()
+    ref.load_state_dict(sd)  # and back
+
+
+def test_checkpoint_names_and_key_layout(tmp_path):
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(64, 1, 1)
+    tr = MUNIT_Trainer(hp)
+    tr.save(str(tmp_path), 41)
+    assert sorted(os.listdir(tmp_path)) == ["dis_00000042.pt", "gen_00000042.pt", "optimizer.pt"]
+    sd = torch.load(tmp_path / "gen_00000042.pt", weights_only=True)
+    assert list(sd) == ["2"] and sd["2"]["enc_style.model.0.conv.weight"].is_contiguous()
+    tr2 = MUNIT_Trainer(hp)
+    assert tr2.resume(str(tmp_path), hp) == 42
+    for a, b in zip(tr.parameters(), tr2.parameters()):
+        assert torch.equal(a, b)
+
+
+_DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from munit_amd.trainer import MUNIT_Trainer
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+r = dist.get_rank()
+flat = torch.arange(10, dtype=torch.float32) * (r + 1)
+MUNIT_Trainer._all_reduce_mean(flat)
+assert torch.allclose(flat, torch.arange(10, dtype=torch.float32) * 1.5), flat
+# bench.py's shard rule: rank r takes samples [r*B, (r+1)*B) of the global batch
+import bench
+xa, xb, ma, mb = bench.make_batch(2, 16, rank=r)
+ga, _, _, _ = bench.make_batch(2, 16, rank=0), None, None, None
+assert xa.shape == (2, 3, 16, 16)
+g = [torch.zeros_like(xa) for _ in range(2)]
+dist.all_gather(g, xa)
+assert not torch.equal(g[0], g[1])          # ranks see different data
+dist.barrier()
+dist.destroy_process_group()
+print("ok", r)
+"""
+
+
+def test_data_parallel_exchange_gloo_world2(tmp_path):
+    """N > 1 path on CPU: mean all-reduce of the flat gradient + per-rank data shards."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(_DP_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              cwd=ROOT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

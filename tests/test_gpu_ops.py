@@ -1,0 +1,258 @@
+"""GPU: every HIP kernel (through the C ABI via munit_amd.ops) against the fp64 CPU oracle
+on the same seeded inputs.  Tolerances (normalised max error = max|d| / max|ref|, SURVEY.md
+section 8c): forward 1e-4 (we assert the tighter 2e-5 the fp32 MFMA chain actually gives),
+gradients 1e-2 (asserted 1e-4)."""
+import pytest
+import torch
+
+from oracle import munit_oracle as O
+from tests.parity import nerr
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-5
+BWD_TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, pad_type, ups, act, B, H, W
+    (3, 64, 7, 1, 3, "reflect", 0, "relu", 2, 20, 24),      # first encoder layer (K=147, unaligned)
+    (64, 128, 4, 2, 1, "reflect", 0, "relu", 2, 16, 16),    # down-sampling
+    (128, 256, 4, 2, 1, "reflect", 0, "none", 1, 12, 20),
+    (256, 256, 3, 1, 1, "reflect", 0, "none", 2, 8, 8),     # resblock conv
+    (256, 128, 5, 1, 2, "reflect", 1, "none", 2, 6, 8),     # upsample x2 + 5x5
+    (128, 64, 5, 1, 2, "reflect", 1, "none", 1, 9, 7),
+    (64, 3, 7, 1, 3, "reflect", 0, "tanh", 2, 16, 12),      # image head (N=3)
+    (3, 64, 4, 2, 1, "reflect", 0, "lrelu", 2, 16, 16),     # D first layer (K=48)
+    (256, 512, 4, 2, 1, "reflect", 0, "lrelu", 2, 4, 4),    # D last layer
+    (512, 1, 1, 1, 0, "zero", 0, "none", 2, 4, 4),          # D head
+    (256, 16, 1, 1, 0, "zero", 0, "none", 3, 1, 1),         # style head on 1x1
+    (32, 48, 3, 1, 1, "zero", 0, "relu", 2, 9, 11),         # zero pad, odd sizes, odd channels
+    (36, 20, 4, 2, 1, "reflect", 0, "none", 2, 9, 11),      # unaligned Cin, odd sizes with stride 2
+    (64, 64, 4, 2, 1, "reflect", 0, "none", 2, 2, 2),       # tiniest reflect case (2x2 -> 1x1)
+]
+
+
+def ref_conv(x, w, b, stride, pad, pad_type, ups, act):
+    if ups:
+        x = O.upsample2(x)
+    return O.conv_block(x, w, b, stride, pad, pad_type, None, act)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%ds%d_%s_u%d_%s" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
+def test_conv_fwd_bwd(case):
+    from munit_amd import ops
+    cin, cout, k, stride, pad, pt, ups, act, B, H, W = case
+    x = rnd((B, cin, H, W), 1)
+    w = rnd((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    b = rnd((cout,), 3, 0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = ref_conv(xr, wr, br, stride, pad, pt, ups, act)
+    dy = rnd(tuple(yr.shape), 4)
+    yr.backward(dy)
+
+    xd = x.float().to(dev()).requires_grad_(True)
+    wd = w.float().to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.float().to(dev()).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride, pad, pt, bool(ups), act)
+    assert tuple(y.shape) == tuple(yr.shape)
+    assert nerr(y, yr) <= FWD_TOL, nerr(y, yr)
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= BWD_TOL, ("dx", nerr(xd.grad, xr.grad))
+    assert nerr(wd.grad, wr.grad) <= BWD_TOL, ("dw", nerr(wd.grad, wr.grad))
+    assert nerr(bd.grad, br.grad) <= BWD_TOL, ("db", nerr(bd.grad, br.grad))
+
+
+def test_conv_wgrad_accumulates_into_buffer():
+    """The trainer path: backward-weight adds into a preallocated buffer (beta = 1)."""
+    from munit_amd import ops
+    x = rnd((2, 64, 8, 8), 1).float().to(dev())
+    w = rnd((64, 64, 3, 3), 2, 0.05).float().to(dev()).contiguous(memory_format=torch.channels_last)
+    b = rnd((64,), 3).float().to(dev())
+    dy = rnd((2, 64, 8, 8), 4).float().to(dev())
+    dw0, db0 = ops.conv2d_wgrad_raw(x, dy, w.shape, 1, 1, "reflect", False)
+    dw, db = dw0.clone(), db0.clone()
+    ops.conv2d_wgrad_raw(x, dy, w.shape, 1, 1, "reflect", False, dw=dw, db=db, beta=1.0)
+    assert nerr(dw, 2 * dw0) <= 1e-6 and nerr(db, 2 * db0) <= 1e-6
+
+
+def test_linear():
+    from munit_amd import ops
+    x = rnd((5, 16), 1)
+    w = rnd((256, 16), 2, 0.2)
+    b = rnd((256,), 3, 0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.clamp_min(torch.nn.functional.linear(xr, wr, br), 0)
+    dy = rnd(tuple(yr.shape), 4)
+    yr.backward(dy)
+    xd, wd, bd = (t.float().to(dev()).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, "relu")
+    assert nerr(y, yr) <= FWD_TOL
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= BWD_TOL
+    assert nerr(wd.grad, wr.grad) <= BWD_TOL
+    assert nerr(bd.grad, br.grad) <= BWD_TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 256, 8, 8), (1, 128, 31, 17), (2, 48, 5, 7)])
+@pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res"])
+def test_instance_norm(shape, mode):
+    from munit_amd import ops
+    B, C, H, W = shape
+    x = rnd(shape, 1, 1.7) + 0.4
+    res = rnd(shape, 5)
+    params = rnd((B, 4 * C), 2) + 0.5
+    w_off, b_off = 3 * C, C
+    xr = x.clone().requires_grad_(True)
+    pr = params.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True)
+    if mode.startswith("adain"):
+        yr = O.adain(xr, pr[:, w_off:w_off + C], pr[:, b_off:b_off + C])
+    else:
+        yr = O.instance_norm(xr)
+    if mode.endswith("relu"):
+        yr = torch.clamp_min(yr, 0)
+    if mode.endswith("res"):
+        yr = yr + rr
+    dy = rnd(shape, 4)
+    yr.backward(dy)
+
+    xd = x.float().to(dev()).requires_grad_(True)
+    pd = params.float().to(dev()).requires_grad_(True)
+    rd = res.float().to(dev()).requires_grad_(True)
+    relu = mode.endswith("relu")
+    residual = rd if mode.endswith("res") else None
+    if mode.startswith("adain"):
+        y = ops.adain(xd, pd, w_off, b_off, relu, residual)
+    else:
+        y = ops.instance_norm(xd, relu, residual)
+    assert nerr(y, yr) <= FWD_TOL, nerr(y, yr)
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= BWD_TOL, nerr(xd.grad, xr.grad)
+    if mode.startswith("adain"):
+        assert nerr(pd.grad, pr.grad) <= BWD_TOL, nerr(pd.grad, pr.grad)
+    if mode.endswith("res"):
+        assert nerr(rd.grad, rr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16), (1, 64, 33, 9), (3, 64, 8, 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layer_norm(shape, relu):
+    from munit_amd import ops
+    B, C, H, W = shape
+    x = rnd(shape, 1, 2.0) - 0.7
+    g = torch.rand(C, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    bt = rnd((C,), 3, 0.3)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, bt))
+    yr = O.munit_layer_norm(xr, gr, br)
+    if relu:
+        yr = torch.clamp_min(yr, 0)
+    dy = rnd(shape, 4)
+    yr.backward(dy)
+    xd, gd, bd = (t.float().to(dev()).requires_grad_(True) for t in (x, g, bt))
+    y = ops.layer_norm(xd, gd, bd, relu)
+    assert nerr(y, yr) <= FWD_TOL, nerr(y, yr)
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= BWD_TOL, nerr(xd.grad, xr.grad)
+    assert nerr(gd.grad, gr.grad) <= BWD_TOL
+    assert nerr(bd.grad, br.grad) <= BWD_TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 3, 9, 13), (2, 3, 2, 2), (1, 5, 1, 4)])
+def test_avgpool(shape):
+    from munit_amd import ops
+    x = rnd(shape, 1)
+    xr = x.clone().requires_grad_(True)
+    yr = O.avgpool_3s2(xr)
+    dy = rnd(tuple(yr.shape), 2)
+    yr.backward(dy)
+    xd = x.float().to(dev()).requires_grad_(True)
+    y = ops.avgpool3s2(xd)
+    assert tuple(y.shape) == tuple(yr.shape)
+    assert nerr(y, yr) <= 1e-6
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= 1e-6
+
+
+def test_global_avgpool():
+    from munit_amd import ops
+    x = rnd((3, 256, 16, 16), 1)
+    xr = x.clone().requires_grad_(True)
+    yr = xr.mean(dim=(2, 3), keepdim=True)
+    dy = rnd(tuple(yr.shape), 2)
+    yr.backward(dy)
+    xd = x.float().to(dev()).requires_grad_(True)
+    y = ops.global_avgpool(xd)
+    assert nerr(y, yr) <= 1e-6
+    y.backward(dy.float().to(dev()))
+    assert nerr(xd.grad, xr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_l1_mean(masked):
+    from munit_amd import ops
+    a, b = rnd((2, 3, 17, 19), 1), rnd((2, 3, 17, 19), 2)
+    m = (torch.rand(2, 1, 17, 19, generator=torch.Generator().manual_seed(3)) > 0.5).double() if masked else None
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr = O.l1_masked(ar, br, m) if masked else O.l1(ar, br)
+    (lr * 12.0).backward()
+    ad, bd = (t.float().to(dev()).requires_grad_(True) for t in (a, b))
+    md = m.float().to(dev()) if masked else None
+    l = ops.l1_mean(ad, bd, md)
+    assert abs(float(l) - float(lr)) <= 1e-6 * abs(float(lr))
+    torch.autograd.backward([l], [torch.tensor(12.0, device=dev())])
+    assert nerr(ad.grad, ar.grad) <= 1e-6 and nerr(bd.grad, br.grad) <= 1e-6
+
+
+def test_l1_mean_content_and_style_shapes():
+    from munit_amd import ops
+    for shape in [(2, 256, 8, 8), (3, 16, 1, 1)]:
+        a, b = rnd(shape, 1), rnd(shape, 2)
+        l = ops.l1_mean(a.float().to(dev()), b.float().to(dev()))
+        assert abs(float(l) - float(O.l1(a, b))) <= 1e-6 * float(O.l1(a, b))
+
+
+def test_mse_const_and_scalar_sum():
+    from munit_amd import ops
+    xs = [rnd((2, 1, 4, 4), 1), rnd((2, 1, 2, 2), 2), rnd((2, 1, 1, 1), 3)]
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    lr = sum(torch.mean((t - 1) ** 2) for t in xr)
+    (3.0 * lr).backward()
+    xd = [t.float().to(dev()).requires_grad_(True) for t in xs]
+    l = ops.scalar_sum([ops.mse_const(t, 1.0) for t in xd])
+    assert abs(float(l) - float(lr)) <= 1e-6 * float(lr)
+    torch.autograd.backward([l], [torch.tensor(3.0, device=dev())])
+    for d, r in zip(xd, xr):
+        assert nerr(d.grad, r.grad) <= 1e-6
+
+
+def test_adam_matches_torch_semantics():
+    from munit_amd import ops
+    n = 1003
+    p, g = rnd((n,), 1), rnd((n,), 2, 0.01)
+    m, v = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    pd, gd = p.float().to(dev()).contiguous(), g.float().to(dev()).contiguous()
+    md, vd = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    pr = p.clone()
+    for step in (1, 2, 3):
+        O.adam_update(pr, g, m, v, step, 1e-4, 0.5, 0.999, 1e-8, 1e-4)
+        ops.adam_step(pd, gd, md, vd, 1e-4, 0.5, 0.999, 1e-8, 1e-4, step)
+    assert float((pd.double().cpu() - pr).abs().max()) <= 1e-7
+    assert nerr(md, m) <= 1e-6 and nerr(vd, v) <= 1e-6
+
+
+def test_cpu_tensor_is_refused():
+    """No CPU fallback: the product path must fail loudly off-device."""
+    from munit_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, "reflect")

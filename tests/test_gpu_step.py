@@ -1,0 +1,106 @@
+"""GPU: module- and step-level parity of the HIP trainer against the oracle and the golden
+fixtures (generated from the reference's network modules)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import munit_oracle as O
+from tests.parity import load_into_trainer, nerr, oracle_states, run_step_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("gs", [1, 0])
+def test_modules_match_golden_forward(golden, gs):
+    """encode / decode / discriminator forward vs the float64 run of the REFERENCE modules
+    (tests/golden/golden_arrays.npz).  Tolerance 1e-4 normalised."""
+    from munit_amd.trainer import MUNIT_Trainer
+    meta, arrays = golden
+    hp = O.default_hp(64, 2, gs)
+    tr = MUNIT_Trainer(dict(hp))
+    load_into_trainer(tr, *oracle_states(hp, torch.float32))
+    tr.to("cuda:0")
+    x_a, x_b, _, _ = O.synthetic_batch(2, 64, seed=7)
+    with torch.no_grad():
+        c, s = tr._enc(x_a.cuda(), 1)
+        x_rec = tr._dec(c, s, 1)
+        c2, s2 = tr._enc(x_b.cuda(), 2)
+        x_ab = tr._dec(c, s2, 2)
+        d = tr.dis_a(x_rec)
+    key = "fwd_gs%d_f64" % gs
+    assert tuple(c.shape) == (2, 256, 16, 16) and tuple(s.shape) == (2, 16, 1, 1)
+    assert nerr(x_rec, torch.from_numpy(arrays[key + "_x_rec"])) <= 1e-4
+    assert nerr(x_ab, torch.from_numpy(arrays[key + "_x_ab"])) <= 1e-4
+    assert nerr(s, torch.from_numpy(arrays[key + "_style"])) <= 1e-4
+    assert nerr(c[:, ::16, ::2, ::2], torch.from_numpy(arrays[key + "_content_slice"])) <= 1e-4
+    for i, o in enumerate(d):
+        assert nerr(o, torch.from_numpy(arrays[key + "_dis%d" % i])) <= 1e-4
+
+
+@pytest.mark.parametrize("gs,iters", [(1, 3), (0, 1)])
+def test_step_matches_oracle(gs, iters):
+    rep = run_step_parity(size=64, batch=2, gen_state=gs, iters=iters, device="cuda:0")
+    print(rep)
+
+
+def test_step_losses_match_golden(golden):
+    """First-iteration losses straight against the fixture produced from the reference modules."""
+    meta, _ = golden
+    rep = run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0")
+    for k, v in meta["step_gs1"]["iters"][0]["losses"].items():
+        assert abs(rep[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, rep[k], v)
+
+
+def test_unequal_hw_and_batch1():
+    """ragged spatial size (H != W, not a multiple of the tile) and batch 1."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(64, 1, 1)
+    gen, dis_a, dis_b = oracle_states(hp, torch.float64)
+    tr = MUNIT_Trainer(dict(hp))
+    load_into_trainer(tr, gen, dis_a, dis_b)
+    tr.to("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = 2 * torch.rand(1, 3, 48, 80, generator=g) - 1
+    view = O.GenView(gen, hp["gen"], True)
+    with torch.no_grad():
+        c_ref, s_ref = view.encode(x.double(), 1)
+        y_ref = view.decode(c_ref, s_ref, 2)
+        c, s = tr.gen.encode(x.cuda(), 1)
+        y = tr.gen.decode(c, s, 2)
+    assert nerr(c, c_ref) <= 1e-4 and nerr(s, s_ref) <= 1e-4 and nerr(y, y_ref) <= 1e-4
+
+
+def test_full_size_properties():
+    """BASELINE config #2 shapes (256x256, B=8), where the oracle is too slow to run in a test:
+    size-independent properties.  (1) adjoint identities <conv(x), dy> = <x, dgrad(dy)> =
+    <w, wgrad(x, dy)> for the two dominant layers (3x3 256->256 @64^2 and upsample+5x5
+    256->128 @128^2); (2) linearity of the convolution; (3) instance norm output has zero
+    mean / unit biased variance per (b, c); (4) bit-identical results run to run."""
+    from munit_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (cin, cout, k, pad, ups, hw) in [(256, 256, 3, 1, False, 64), (256, 128, 5, 2, True, 64)]:
+        x = torch.randn(8, cin, hw, hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        x2 = torch.randn(8, cin, hw, hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dev)
+        w = w.contiguous(memory_format=torch.channels_last)
+        y = ops.conv2d_fwd_raw(x, w, None, 1, pad, "reflect", ups, "none")
+        y_again = ops.conv2d_fwd_raw(x, w, None, 1, pad, "reflect", ups, "none")
+        assert torch.equal(y, y_again)
+        dy = torch.randn(y.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        dx = ops.conv2d_dgrad_raw(dy, w, x.shape, 1, pad, "reflect", ups)
+        dw, _ = ops.conv2d_wgrad_raw(x, dy, w.shape, 1, pad, "reflect", ups, want_bias=False)
+        a = float((y.double() * dy.double()).sum())
+        b = float((x.double() * dx.double()).sum())
+        c = float((w.double() * dw.double()).sum())
+        scale = float(y.double().norm() * dy.double().norm())
+        assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
+        y2 = ops.conv2d_fwd_raw(x2, w, None, 1, pad, "reflect", ups, "none")
+        y12 = ops.conv2d_fwd_raw((0.5 * x - 2.0 * x2).contiguous(memory_format=torch.channels_last), w, None, 1,
+                                 pad, "reflect", ups, "none")
+        assert nerr(y12, 0.5 * y.double() - 2.0 * y2.double()) <= 1e-5
+    x = (torch.randn(8, 256, 64, 64, generator=g) * 3 + 1).to(dev).contiguous(memory_format=torch.channels_last)
+    y = ops.instance_norm(x)
+    m = y.double().mean(dim=(2, 3))
+    v = (y.double() ** 2).mean(dim=(2, 3)) - m ** 2
+    assert float(m.abs().max()) <= 1e-5 and float((v - 1).abs().max()) <= 1e-4

@@ -5,7 +5,10 @@
 // -- per-thread fp32 accumulators over a channel quad, wavefront/LDS reduction across the
 // pixel lanes of the block -- and an apply kernel that folds the split partials in its
 // prologue (kept in LDS) and streams float4s.  Sums are taken relative to a pivot (the
-// first element of the plane) so the variance does not cancel catastrophically.
+// first element of the plane) so the variance does not cancel catastrophically, and every
+// statistic is accumulated in fp64 (free at HBM-bound rates): an fp32 error in a per-channel
+// mean is the same for every pixel of the plane and would add up coherently in the weight
+// gradients downstream.
 #include "common.h"
 
 namespace {
@@ -38,9 +41,10 @@ inline int pick_split(int B, int HW) {
 // instance norm
 // ---------------------------------------------------------------------------------------
 // partial[b][split][2][C] : sum(x - pivot), sum((x - pivot)^2), pivot = x[b][0][c]
-__global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+__global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                       int HW, int C, int nsplit) {
-  extern __shared__ float sm[];  // [PL][QB*4][2]
+  extern __shared__ double smd[];  // [PL][QB*4][2]
+  double* sm = smd;
   const Lay L = make_lay(C);
   const int b = blockIdx.y, sp = blockIdx.x;
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
@@ -48,28 +52,31 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ 
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const float* xb = x + (long long)b * HW * C;
   for (int qq = q; qq < L.CQ; qq += L.QB) {
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
       const f32x4 piv = *reinterpret_cast<const f32x4*>(xb + qq * 4);
       for (int p = p0 + pl; p < p1; p += L.PL) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C + qq * 4) - piv;
-        s1 += v;
-        s2 += v * v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += (double)v[e];
+          s2[e] += (double)v[e] * (double)v[e];
+        }
       }
-      float* d = sm + ((pl * L.QB + q) * 8);
+      double* d = sm + ((pl * L.QB + q) * 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
     }
     __syncthreads();
     if (pl == 0) {
       for (int l = 1; l < L.PL; ++l) {
-        const float* d = sm + ((l * L.QB + q) * 8);
+        const double* d = sm + ((l * L.QB + q) * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
       }
-      float* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
-      *reinterpret_cast<f32x4*>(o) = s1;
-      *reinterpret_cast<f32x4*>(o + C) = s2;
+      double* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = s1[e]; o[C + e] = s2[e]; }
     }
     __syncthreads();
   }
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ 
 
 // y = act((x-mean)*rstd*w + b) + residual ; writes stats[b][c] = (mean, rstd) from split 0
 __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      const float* __restrict__ partial, float* __restrict__ stats,
+                                                      const double* __restrict__ partial, float* __restrict__ stats,
                                                       int HW, int C, int nsplit, const float* __restrict__ adain,
                                                       int ad_ld, int w_off, int b_off,
                                                       const float* __restrict__ residual, int relu, float eps) {
@@ -87,18 +94,18 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ 
   const int b = blockIdx.y, sp = blockIdx.x;
   const float* xb = x + (long long)b * HW * C;
   for (int c = threadIdx.x; c < C; c += NT) {
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     for (int k = 0; k < nsplit; ++k) {
-      const float* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+      const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
       s1 += o[c];
       s2 += o[C + c];
     }
-    const float inv_n = 1.f / (float)HW;
-    const float d = s1 * inv_n;
-    const float mean = xb[c] + d;
-    float var = s2 * inv_n - d * d;
-    var = var > 0.f ? var : 0.f;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const double inv_n = 1.0 / (double)HW;
+    const double d = s1 * inv_n;
+    const float mean = (float)((double)xb[c] + d);
+    double var = s2 * inv_n - d * d;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float w = 1.f, bb = 0.f;
     if (adain != nullptr) {
       w = adain[(long long)b * ad_ld + w_off + c];
@@ -134,10 +141,11 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ 
 
 // backward partials: partial[b][split][2][C] : sum(g), sum(g*xhat), g = dy * relu'(pre)
 __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ stats, float* __restrict__ partial,
+                                                          const float* __restrict__ stats, double* __restrict__ partial,
                                                           int HW, int C, int nsplit, const float* __restrict__ adain,
                                                           int ad_ld, int w_off, int b_off, int relu) {
-  extern __shared__ float sm[];
+  extern __shared__ double smd[];
+  double* sm = smd;
   const Lay L = make_lay(C);
   const int b = blockIdx.y, sp = blockIdx.x;
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restric
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const long long base = (long long)b * HW * C;
   for (int qq = q; qq < L.CQ; qq += L.QB) {
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
       f32x4 mean, rstd, w, bb;
 #pragma unroll
@@ -164,23 +172,26 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
         }
-        s1 += g;
-        s2 += g * xh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += (double)g[e];
+          s2[e] += (double)g[e] * (double)xh[e];
+        }
       }
-      float* d = sm + ((pl * L.QB + q) * 8);
+      double* d = sm + ((pl * L.QB + q) * 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
     }
     __syncthreads();
     if (pl == 0) {
       for (int l = 1; l < L.PL; ++l) {
-        const float* d = sm + ((l * L.QB + q) * 8);
+        const double* d = sm + ((l * L.QB + q) * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
       }
-      float* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
-      *reinterpret_cast<f32x4*>(o) = s1;
-      *reinterpret_cast<f32x4*>(o + C) = s2;
+      double* o = partial + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = s1[e]; o[C + e] = s2[e]; }
     }
     __syncthreads();
   }
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restric
 // dx = rstd*w*(g - mean(g) - xhat*mean(g*xhat)); d_adain weight = sum(g*xhat), bias = sum(g)
 __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ stats,
-                                                          const float* __restrict__ partial, float* __restrict__ dx,
+                                                          const double* __restrict__ partial, float* __restrict__ dx,
                                                           int HW, int C, int nsplit, const float* __restrict__ adain,
                                                           float* __restrict__ d_adain, int ad_ld, int w_off, int b_off,
                                                           int relu) {
@@ -202,9 +213,9 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restric
   float* s_a2 = sm + 5 * C;
   const int b = blockIdx.y, sp = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += NT) {
-    float a1 = 0.f, a2 = 0.f;
+    double a1 = 0.0, a2 = 0.0;
     for (int k = 0; k < nsplit; ++k) {
-      const float* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+      const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
       a1 += o[c];
       a2 += o[C + c];
     }
@@ -213,12 +224,12 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restric
     s_w[c] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
     s_b[c] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
     if (sp == 0 && d_adain != nullptr) {
-      d_adain[(long long)b * ad_ld + w_off + c] = a2;
-      d_adain[(long long)b * ad_ld + b_off + c] = a1;
+      d_adain[(long long)b * ad_ld + w_off + c] = (float)a2;
+      d_adain[(long long)b * ad_ld + b_off + c] = (float)a1;
     }
-    const float inv_n = 1.f / (float)HW;
-    s_a1[c] = a1 * inv_n;
-    s_a2[c] = a2 * inv_n;
+    const double inv_n = 1.0 / (double)HW;
+    s_a1[c] = (float)(a1 * inv_n);
+    s_a2[c] = (float)(a2 * inv_n);
   }
   __syncthreads();
   const int CQ = C >> 2;
@@ -248,34 +259,35 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------
 // MUNIT LayerNorm
 // ---------------------------------------------------------------------------------------
-__device__ inline float block_sum(float v, float* red) {
-  v = wave_sum(v);
+__device__ inline double block_sum(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
-  float t = 0.f;
+  double t = 0.0;
 #pragma unroll
   for (int i = 0; i < NT / 64; ++i) t += red[i];
   return t;
 }
 
 // partial[b][split][2]: sum(x-pivot), sum((x-pivot)^2), pivot = x[b][0]
-__global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+__global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                       long long n_per_sample, int nsplit) {
-  __shared__ float red[NT / 64];
+  __shared__ double red[NT / 64];
   const int b = blockIdx.y, sp = blockIdx.x;
   const float* xb = x + (long long)b * n_per_sample;
   const long long nq = n_per_sample >> 2;
   const long long per = (nq + nsplit - 1) / nsplit;
   const long long q0 = sp * per, q1 = min(nq, q0 + per);
   const float piv = xb[0];
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;
   for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
     f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float d = v[e] - piv;
+      double d = (double)(v[e] - piv);
       s1 += d;
       s2 += d * d;
     }
@@ -288,12 +300,12 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ 
   }
 }
 
-__device__ inline void ln_finish(const float* partial, const float* xb, int b, int nsplit, long long n,
+__device__ inline void ln_finish(const double* partial, const float* xb, int b, int nsplit, long long n,
                                  float* mean, float* sigma) {
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < nsplit; ++k) {
-    s1 += (double)partial[((long long)b * nsplit + k) * 2];
-    s2 += (double)partial[((long long)b * nsplit + k) * 2 + 1];
+    s1 += partial[((long long)b * nsplit + k) * 2];
+    s2 += partial[((long long)b * nsplit + k) * 2 + 1];
   }
   const double d = s1 / (double)n;
   double var = (s2 - s1 * d) / (double)(n - 1);  // unbiased (torch.std default), networks.py:868/871
@@ -303,7 +315,7 @@ __device__ inline void ln_finish(const float* partial, const float* xb, int b, i
 }
 
 __global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      const float* __restrict__ partial, float* __restrict__ stats,
+                                                      const double* __restrict__ partial, float* __restrict__ stats,
                                                       int HW, int C, int nsplit, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int relu, float eps) {
   extern __shared__ float sm[];  // scale[C], shift[C]
@@ -344,12 +356,13 @@ __global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ 
 // samp[2] = sum(g*gamma), sum(g*gamma*xn).
 // cpart layout [b][split][2][C], spart layout [b][split][2]
 __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ stats, float* __restrict__ cpart,
-                                                          float* __restrict__ spart, int HW, int C, int nsplit,
+                                                          const float* __restrict__ stats, double* __restrict__ cpart,
+                                                          double* __restrict__ spart, int HW, int C, int nsplit,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu, float eps) {
-  extern __shared__ float sm[];  // [PL][QB*4][2]
-  __shared__ float red[NT / 64];
+  extern __shared__ double smd[];  // [PL][QB*4][2]
+  double* sm = smd;
+  __shared__ double red[NT / 64];
   const Lay L = make_lay(C);
   const int b = blockIdx.y, sp = blockIdx.x;
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
@@ -358,9 +371,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restric
   const long long base = (long long)b * HW * C;
   const float mean = stats[b * 2];
   const float inv = 1.f / (stats[b * 2 + 1] + eps);
-  float t1 = 0.f, t2 = 0.f;
+  double t1 = 0.0, t2 = 0.0;
   for (int qq = q; qq < L.CQ; qq += L.QB) {
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + qq * 4);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + qq * 4);
@@ -372,28 +385,31 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
         }
-        s1 += g * xn;
-        s2 += g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += (double)g[e] * (double)xn[e];
+          s2[e] += (double)g[e];
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        t1 += s2[e] * gm[e];
-        t2 += s1[e] * gm[e];
+        t1 += s2[e] * (double)gm[e];
+        t2 += s1[e] * (double)gm[e];
       }
-      float* d = sm + ((pl * L.QB + q) * 8);
+      double* d = sm + ((pl * L.QB + q) * 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
     }
     __syncthreads();
     if (pl == 0) {
       for (int l = 1; l < L.PL; ++l) {
-        const float* d = sm + ((l * L.QB + q) * 8);
+        const double* d = sm + ((l * L.QB + q) * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] += d[4 + e]; }
       }
-      float* o = cpart + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
-      *reinterpret_cast<f32x4*>(o) = s1;
-      *reinterpret_cast<f32x4*>(o + C) = s2;
+      double* o = cpart + ((long long)(b * nsplit + sp) * 2) * C + qq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = s1[e]; o[C + e] = s2[e]; }
     }
     __syncthreads();
   }
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restric
 // dx = inv*(h - S1/N) - S2*xn/((N-1)*sigma), h = g*gamma
 __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ stats,
-                                                          const float* __restrict__ spart, float* __restrict__ dx,
+                                                          const double* __restrict__ spart, float* __restrict__ dx,
                                                           int HW, int C, int nsplit, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu, float eps) {
   const int b = blockIdx.y, sp = blockIdx.x;
@@ -418,8 +434,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
   const float inv = 1.f / (sigma + eps);
   double S1 = 0.0, S2 = 0.0;
   for (int k = 0; k < nsplit; ++k) {
-    S1 += (double)spart[((long long)b * nsplit + k) * 2];
-    S2 += (double)spart[((long long)b * nsplit + k) * 2 + 1];
+    S1 += spart[((long long)b * nsplit + k) * 2];
+    S2 += spart[((long long)b * nsplit + k) * 2 + 1];
   }
   const float c1 = (float)(S1 / (double)n);
   const float c2 = sigma > 0.f ? (float)(S2 / ((double)(n - 1) * (double)sigma)) : 0.f;
@@ -444,23 +460,23 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
 }
 
 // dgamma[c] = acc*dgamma[c] + sum_{b,split} cpart[..][0][c]; dbeta likewise with [1]
-__global__ void ln_bwd_param_kernel(const float* __restrict__ cpart, float* __restrict__ dgamma,
+__global__ void ln_bwd_param_kernel(const double* __restrict__ cpart, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int C, int nblk, float acc) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float g = 0.f, bt = 0.f;
+  double g = 0.0, bt = 0.0;
   for (int k = 0; k < nblk; ++k) {
     g += cpart[((long long)k * 2) * C + c];
     bt += cpart[((long long)k * 2 + 1) * C + c];
   }
-  dgamma[c] = (acc != 0.f ? acc * dgamma[c] : 0.f) + g;
-  dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + bt;
+  dgamma[c] = (acc != 0.f ? acc * dgamma[c] : 0.f) + (float)g;
+  dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + (float)bt;
 }
 
 }  // namespace
 
 extern "C" size_t munit_instnorm_workspace_bytes(int B, int HW, int C) {
-  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256);
+  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256);
 }
 
 extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
@@ -475,9 +491,9 @@ extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B,
   }
   hipStream_t st = (hipStream_t)stream;
   const int ns = pick_split(B, HW);
-  float* partial = reinterpret_cast<float*>(ws);
+  double* partial = reinterpret_cast<double*>(ws);
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(in_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+  hipLaunchKernelGGL(in_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      partial, HW, C, ns);
   MUNIT_CHECK_LAUNCH("in_stats");
   hipLaunchKernelGGL(in_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, partial,
@@ -497,9 +513,9 @@ extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* 
   }
   hipStream_t st = (hipStream_t)stream;
   const int ns = pick_split(B, HW);
-  float* partial = reinterpret_cast<float*>(ws);
+  double* partial = reinterpret_cast<double*>(ws);
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(in_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+  hipLaunchKernelGGL(in_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_stats");
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, stats,
@@ -509,8 +525,8 @@ extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* 
 }
 
 extern "C" size_t munit_layernorm_workspace_bytes(int B, int HW, int C) {
-  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256) +
-         align_up((size_t)B * MAX_SPLIT * 2 * sizeof(float), 256);
+  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256) +
+         align_up((size_t)B * MAX_SPLIT * 2 * sizeof(double), 256);
 }
 
 extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
@@ -525,7 +541,7 @@ extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B
   }
   hipStream_t st = (hipStream_t)stream;
   const int ns = pick_split(B, HW);
-  float* spart = reinterpret_cast<float*>(ws);
+  double* spart = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(ns, B), dim3(NT), 0, st, x, spart, (long long)HW * C, ns);
   MUNIT_CHECK_LAUNCH("ln_stats");
   hipLaunchKernelGGL(ln_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, spart, stats,
@@ -546,11 +562,11 @@ extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float*
   }
   hipStream_t st = (hipStream_t)stream;
   const int ns = pick_split(B, HW);
-  float* cpart = reinterpret_cast<float*>(ws);
-  float* spart = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
-                                          align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(float), 256));
+  double* cpart = reinterpret_cast<double*>(ws);
+  double* spart = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) +
+                                            align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256));
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(float), st, x,
+  hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      dy, stats, cpart, spart, HW, C, ns, gamma, beta, relu, eps);
   MUNIT_CHECK_LAUNCH("ln_bwd_stats");
   hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(ns, B), dim3(NT), 0, st, x, dy, stats, spart, dx, HW, C, ns, gamma,

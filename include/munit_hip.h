@@ -151,9 +151,11 @@ int munit_weighted_sum(const float* const* terms, const float* w, int n, float* 
 /* ------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam as configured at scripts/trainer.py:109-120: L2-coupled
  * weight_decay, amsgrad off) over one flat fp32 buffer of n elements.  step >= 1.
+ * Hyper-parameters are doubles, as in torch: beta2 = 0.999 and 1 - beta2 = 0.001 are each rounded
+ * to fp32 separately (computing 1 - (float)beta2 in fp32 is off by 1.3e-5 relative).
  * ------------------------------------------------------------------------------------ */
-int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int step, munit_stream_t stream);
+int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int step, munit_stream_t stream);
 
 /* y[i] = alpha * x[i] (+ y[i] if accumulate); used for the 1/world gradient averaging. */
 int munit_scale(const float* x, float* y, size_t n, float alpha, int accumulate, munit_stream_t stream);

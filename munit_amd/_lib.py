@@ -6,7 +6,7 @@ CPU test-suite can check that every declared symbol is exported.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmunit_hip.so")
@@ -56,7 +56,8 @@ SIGNATURES = {
     "munit_mse_const_fwd": (c_int, [_P, c_float, c_size_t, _P, _P, c_size_t, _P]),
     "munit_mse_const_bwd": (c_int, [_P, c_float, c_size_t, _P, _P, _P]),
     "munit_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _P, _P]),
-    "munit_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "munit_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int,
+                                _P]),
     "munit_scale": (c_int, [_P, _P, c_size_t, c_float, c_int, _P]),
 }
 

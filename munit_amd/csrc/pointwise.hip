@@ -191,7 +191,7 @@ __global__ void weighted_sum_kernel(WsumArgs a, float* out) {
 // torch.optim.Adam single-tensor update order (L2 weight decay folded into the gradient).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
-                            float wd, float bc2_sqrt) {
+                            float wd, float bc2_sqrt, float omb1, float omb2) {
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -202,8 +202,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gr = gg[e] + wd * pp[e];
-      mm[e] = mm[e] + (gr - mm[e]) * (1.f - beta1);
-      vv[e] = vv[e] * beta2 + (1.f - beta2) * gr * gr;
+      mm[e] = mm[e] + (gr - mm[e]) * omb1;
+      vv[e] = vv[e] * beta2 + omb2 * gr * gr;
       float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       pp[e] = pp[e] - step_size * (mm[e] / denom);
     }
@@ -214,8 +214,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   // tail
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float gr = g[i] + wd * p[i];
-    float mm = m[i] + (gr - m[i]) * (1.f - beta1);
-    float vv = v[i] * beta2 + (1.f - beta2) * gr * gr;
+    float mm = m[i] + (gr - m[i]) * omb1;
+    float vv = v[i] * beta2 + omb2 * gr * gr;
     float denom = sqrtf(vv) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mm / denom);
     m[i] = mm;
@@ -340,18 +340,19 @@ extern "C" int munit_weighted_sum(const float* const* terms, const float* w, int
   return MUNIT_OK;
 }
 
-extern "C" int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, int step, munit_stream_t stream) {
+extern "C" int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, int step, munit_stream_t stream) {
   MUNIT_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad args");
   MUNIT_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                       ((uintptr_t)v % 16 == 0),
                   "adam_step: buffers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long long)n, 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
-                     (long long)n, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
+                     (long long)n, step_size, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc2_sqrt,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2));
   MUNIT_CHECK_LAUNCH("adam");
   return MUNIT_OK;
 }

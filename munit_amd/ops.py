@@ -470,9 +470,8 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     lib = _lib.load()
     for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
         _require(t, "adam " + nm)
-    _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), c_float(lr), c_float(beta1),
-                                   c_float(beta2), c_float(eps), c_float(weight_decay), int(step), _stream()),
-               "adam_step")
+    _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                   float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
 def scale_(x, alpha):

@@ -19,6 +19,40 @@ def nerr(a, ref):
     return float((a - ref).abs().max()) / den
 
 
+def l2err(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((a - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+class GradCheck:
+    """Gradient tolerance vs the fp64 oracle.  SURVEY.md section 8c proposes 1e-2 normalised max
+    error.  One effect that bound does not cover was measured on the box (tools/diag_grad.py):
+    a ReLU pre-activation within fp32 noise of 0 takes the other branch than in fp64, which
+    switches ONE element of an upstream gradient on or off and shows up as an isolated error of a
+    few 1e-2 of max|g| in one output-channel row of one weight gradient (a few such elements per
+    million exist in every fp32 implementation, torch's own included).  So: relative L2 <= 5e-3
+    for every tensor (torch-CPU fp32 vs fp64 on the same step measures 4e-4..1.5e-3, worst on the
+    first-layer convs; this path measures up to 3e-3 there -- its conv sums are one k-ordered fp32
+    fma chain per output, torch's are blocked),
+    normalised max <= 1e-2 for all but at most `max_kinks` tensors, and those must stay <= 1e-1."""
+
+    L2_TOL = 5e-3
+
+    def __init__(self, max_kinks=3):
+        self.max_kinks, self.kinks, self.worst_max, self.worst_l2 = max_kinks, [], 0.0, 0.0
+
+    def add(self, name, mine, ref, check=True):
+        e, l2 = nerr(mine, ref), l2err(mine, ref)
+        self.worst_max, self.worst_l2 = max(self.worst_max, e), max(self.worst_l2, l2)
+        if check:
+            assert l2 <= self.L2_TOL, ("grad l2", name, l2)
+            if e > 1e-2:
+                assert e <= 1e-1, ("grad max", name, e)
+                self.kinks.append((name, e))
+                assert len(self.kinks) <= self.max_kinks, ("too many outliers", self.kinks)
+
+
 def oracle_states(hp, dtype):
     gs = hp["gen_state"]
     if gs == 1:
@@ -67,7 +101,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
                     step_size=2, check=True):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
-    losses 1e-5 relative, gradients 1e-2 normalised; weights after Adam: see the comment at the end)."""
+    losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end)."""
     from munit_amd.trainer import MUNIT_Trainer
 
     hp = O.default_hp(size, batch, gen_state)
@@ -84,54 +118,76 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
     gnames, dnames = trainer_named_params(tr)
     null = set()  # parameters whose true gradient is identically zero (bias ahead of IN/AdaIN):
     # Adam turns their rounding noise into +-lr steps on both sides, so their values are not comparable
+    o_gen, o_dis = orc.opt["gen"]["params"], orc.opt["dis"]["params"]
     for it in range(iters):
+        if it > 0:
+            # Re-synchronise: the oracle continues from the HIP trainer's weights (its own Adam moments
+            # are kept).  Without this the two runs drift chaotically -- torch's own fp32 vs fp64 runs of
+            # this step differ by 1.4e-2 in loss_gen_adv after 3 iterations -- because Adam's early
+            # steps are sign-like; with it every iteration is a fresh one-step comparison while the
+            # moments, step counters and LR schedule still carry over.
+            with torch.no_grad():
+                for (n, p), q in list(zip(gnames, o_gen)) + list(zip(dnames, o_dis)):
+                    q.copy_(p.detach().to(oracle_dtype).cpu())
+        gc = GradCheck()
         tr.update_learning_rate()
         orc.update_learning_rate()
+        assert abs(tr.gen_opt.param_groups[0]["lr"] - orc._lr()) < 1e-15
+        before = [p.detach().double().cpu().clone() for _, p in gnames + dnames]
         tr.dis_update(dx_a, dx_b, hp)
         d_ref = orc.dis_update(ox[0], ox[1])
-        if it == 0:
-            for (n, p), g in zip(dnames, d_ref):
-                e = nerr(p._munit_grad, g)
-                rep["grad_nerr"] = max(rep["grad_nerr"], e)
-                if check:
-                    assert e <= 1e-2 or float(g.abs().max()) < 1e-9, ("dis grad", n, e)
+        for (n, p), g in zip(dnames, d_ref):
+            gc.add("dis." + n, p._munit_grad, g, check)
+        # D just took an Adam step on both sides; its sign-like noise (see below) would otherwise leak
+        # into every generator gradient through the adversarial term (measured: a uniform ~8e-3
+        # relative L2 on all tensors downstream of x_ba / x_ab).  Compare the step, then hand the
+        # oracle the HIP discriminator weights so gen_update is compared on identical networks.
+        d_step = [(n, p.detach().double().cpu(), q.detach().clone()) for (n, p), q in zip(dnames, o_dis)]
+        with torch.no_grad():
+            for (n, p), q in zip(dnames, o_dis):
+                q.copy_(p.detach().to(oracle_dtype).cpu())
         tr.gen_update(dx_a, dx_b, hp, dm_a, dm_b)
         g_ref = orc.gen_update(ox[0], ox[1], ox[2], ox[3])
-        if it == 0:
-            for (n, p), g in zip(gnames, g_ref):
-                if g is None:
-                    continue
-                gmax = float(g.abs().max())
-                e = nerr(p._munit_grad, g)
-                # gradients that are mathematically zero (conv bias ahead of an instance norm)
-                # hold only rounding noise on both sides
-                if gmax < 1e-7:
-                    assert float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
-                    null.add(n)
-                    continue
-                rep["grad_nerr"] = max(rep["grad_nerr"], e)
-                if check:
-                    assert e <= 1e-2, ("gen grad", n, e, gmax)
+        for (n, p), g in zip(gnames, g_ref):
+            if g is None:
+                continue
+            gmax = float(g.abs().max())
+            # gradients that are mathematically zero (conv bias ahead of an instance norm)
+            # hold only rounding noise on both sides
+            if gmax < 1e-7:
+                assert float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
+                null.add(n)
+                continue
+            gc.add("gen." + n, p._munit_grad, g, check)
+        rep["grad_nerr"] = max(rep["grad_nerr"], gc.worst_max)
+        rep["grad_l2"] = max(rep.get("grad_l2", 0.0), gc.worst_l2)
+        rep.setdefault("grad_kinks", []).extend(gc.kinks)
         for k, v in orc.losses.items():
-            mine = float(getattr(tr, k))
+            mine = float(getattr(tr, k).detach())
             rel = abs(mine - float(v)) / max(1.0, abs(float(v)))
             rep["loss_rel"] = max(rep["loss_rel"], rel)
             rep[k] = mine
             if check:
-                assert rel <= 1e-5 * (1 if it == 0 else 50), (it, k, mine, float(v))
-    # Weights after Adam.  Adam's first steps are sign-like (|step| ~ lr whatever |g| is), so an
-    # element whose gradient is below fp32 noise may step the other way: bound = a few lr per
-    # iteration in absolute terms, and a relative L2 error over each tensor for the bulk.
-    rep["weight_abs"] = 0.0
-    rep["weight_l2"] = 0.0
-    for (n, p), q in list(zip(gnames, orc.opt["gen"]["params"])) + list(zip(dnames, orc.opt["dis"]["params"])):
-        if n in null:
-            continue
-        a, r = p.detach().double().cpu(), q.detach().double()
-        rep["weight_abs"] = max(rep["weight_abs"], float((a - r).abs().max()))
-        rep["weight_l2"] = max(rep["weight_l2"], float((a - r).norm() / r.norm().clamp_min(1e-30)))
+                assert rel <= 1e-5, (it, k, mine, float(v), rel)
+        # Adam moments (linear in the gradients, so not sign-sensitive) and the weight step.
+        # Adam's first steps are sign-like (|step| ~ lr whatever |g| is), so an element whose
+        # gradient is below fp32 noise may step the other way: the step is bounded in absolute
+        # terms (a few lr) and in relative L2 over each tensor.
+        for opt_mine, names_, o_key in ((tr.gen_opt, gnames, "gen"), (tr.dis_opt, dnames, "dis")):
+            o = orc.opt[o_key]
+            assert opt_mine._step == o["step"] == it + 1
+            for (n, p), (mv, vv), om, ov, q in zip(names_, opt_mine._views, o["m"], o["v"], o["params"]):
+                if n in null:
+                    continue
+                rep["moment_l2"] = max(rep.get("moment_l2", 0.0), l2err(mv, om), l2err(vv, ov))
+                a, r = p.detach().double().cpu(), q.detach().double()
+                if o_key == "dis":  # the oracle's D was overwritten after its step: use the saved pair
+                    _, a, r = d_step[[x[0] for x in d_step].index(n)]
+                rep["weight_abs"] = max(rep.get("weight_abs", 0.0), float((a - r).abs().max()))
+                rep["weight_l2"] = max(rep.get("weight_l2", 0.0), float((a - r).norm() / r.norm().clamp_min(1e-30)))
+        if check:
+            assert rep["moment_l2"] <= 2 * GradCheck.L2_TOL, rep["moment_l2"]
+            assert rep["weight_abs"] <= 4.0 * hp["lr"], rep["weight_abs"]
+            assert rep["weight_l2"] <= 2e-3, rep["weight_l2"]
     rep["weight_nerr"] = rep["weight_abs"]
-    if check:
-        assert rep["weight_abs"] <= 4.0 * hp["lr"] * iters, rep["weight_abs"]
-        assert rep["weight_l2"] <= 2e-3, rep["weight_l2"]
     return rep

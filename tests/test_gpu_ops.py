@@ -248,8 +248,8 @@ def test_adam_matches_torch_semantics():
         O.adam_update(pr, g, m, v, step, 1e-4, 0.5, 0.999, 1e-8, 1e-4)
         ops.adam_step(pd, gd, md, vd, 1e-4, 0.5, 0.999, 1e-8, 1e-4, step)
     # p is O(1) in fp32: each of the 3 updates rounds to ~6e-8 * |p|
-    assert float((pd.double().cpu() - pr).abs().max()) <= 2e-6
-    assert nerr(md, m) <= 1e-6 and nerr(vd, v) <= 1e-6
+    ep, em, ev = float((pd.double().cpu() - pr).abs().max()), nerr(md, m), nerr(vd, v)
+    assert ep <= 2e-6 and em <= 1e-6 and ev <= 1e-6, (ep, em, ev)
 
 
 def test_cpu_tensor_is_refused():

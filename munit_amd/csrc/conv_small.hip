@@ -1,0 +1,254 @@
+// Convolutions with a tiny channel count on one side (the 64->3 image head of the decoder,
+// networks.py:548-559, its weight gradient, and the data gradient of the 3->64 first encoder
+// layers, networks.py:446-450/484-488).  With N = 3 an MFMA tile would be >90 % padding and the
+// im2col A-operand (49x the input) would be streamed for 6 useful FLOP per 4 bytes, so these run on
+// the vector ALUs (same fp32 peak as the f32 MFMA on gfx950):
+//   * forward (conv_patch_fwd_kernel): one thread per output pixel, a (4+K-1) x (64+K-1) halo patch of
+//     16 input channels staged in LDS as float4 planes (adjacent lanes = adjacent pixels => conflict-free
+//     ds_read_b128), the weights are wave-uniform so they arrive through scalar loads and every
+//     ds_read_b128 feeds 4*CO v_fma with an SGPR operand; no cross-lane reduction at all;
+//   * backward-weight (conv_lanes_wgrad_kernel): channel-per-lane; wave (b, rows, kh) owns
+//     dw[:, kh, :, ci] (CO*K accumulators), slides a 1 x K window of its input row in registers
+//     (one coalesced 256-byte load per pixel), dy values are fetched one pixel per lane and broadcast
+//     with v_readlane; partial results go to slabs summed in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+struct SmallParams {
+  const float* x;     // [B][H][W][Cin]
+  const float* w;     // [CO][K][K][Cin]
+  const float* bias;  // [CO] or null
+  const float* dy;    // wgrad: [B][Ho][Wo][CO]
+  float* y;           // fwd:  [B][Ho][Wo][CO]
+  float* slab;        // wgrad: [rows][CO*K*K*Cin + CO]
+  int B, H, W, Cin, Ho, Wo;
+  int pad, reflect, act;
+  float slope;
+  int tiles_x, tiles_y;  // fwd
+  int rows_per_unit, units_per_img;  // wgrad
+};
+
+__device__ inline int map_coord(int v, int n, int reflect) {
+  if (v < 0) return reflect ? -v : -1;
+  if (v >= n) return reflect ? 2 * n - 2 - v : -1;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: thread per pixel, LDS halo patch, scalar weights.  Cin % 16 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int CO, int K>
+__global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
+  constexpr int TW = 64, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PLANE = PH * PW;
+  __shared__ f32x4 patch[4 * PLANE];  // [c4][row][col]
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int ow0 = tile_x * TW, oh0 = tile_y * TH;
+  const float* xb = p.x + (long long)b * p.H * p.W * p.Cin;
+  const float* __restrict__ wg = p.w;
+
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+
+  for (int ch0 = 0; ch0 < p.Cin; ch0 += 16) {
+    __syncthreads();
+    for (int e = tid; e < 4 * PLANE; e += 256) {
+      const int c4 = e & 3;
+      const int pix = e >> 2;
+      const int pr = pix / PW, pc = pix - pr * PW;
+      const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
+      const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ih >= 0 && iw >= 0) v = *reinterpret_cast<const f32x4*>(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
+      patch[c4 * PLANE + pr * PW + pc] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+#pragma unroll 1
+      for (int c4 = 0; c4 < 4; ++c4) {   // one c4 per trip keeps the K*CO*4 scalar weights within the SGPR file
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const f32x4 xv = patch[c4 * PLANE + (ty + kh) * PW + tx + kw];
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            // wave-uniform address -> scalar load
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wg + ((long long)(c * K + kh) * K + kw) * p.Cin + ch0 + c4 * 4);
+            acc[c] = fmaf(wv[0], xv[0], acc[c]);
+            acc[c] = fmaf(wv[1], xv[1], acc[c]);
+            acc[c] = fmaf(wv[2], xv[2], acc[c]);
+            acc[c] = fmaf(wv[3], xv[3], acc[c]);
+          }
+        }
+      }
+    }
+  }
+  const int oh = oh0 + ty, ow = ow0 + tx;
+  if (oh < p.Ho && ow < p.Wo) {
+    float* yo = p.y + (((long long)b * p.Ho + oh) * p.Wo + ow) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      float v = acc[c] + (p.bias != nullptr ? p.bias[c] : 0.f);
+      yo[c] = apply_act(v, p.act, p.slope);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-weight: channel per lane; unit = (b, band of rows_per_unit output rows, kh, channel group)
+// ---------------------------------------------------------------------------------------------
+template <int CO, int K>
+__global__ __launch_bounds__(256) void conv_lanes_wgrad_kernel(SmallParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = p.Cin >> 6;
+  const long long unit = (long long)blockIdx.x * 4 + wv;
+  const long long per_band = (long long)K * G;
+  const long long nunits = (long long)p.B * p.units_per_img * per_band;
+  if (unit >= nunits) return;  // no block-level synchronisation below
+  const int g = (int)(unit % G);
+  const int kh = (int)((unit / G) % K);
+  const long long band = unit / per_band;          // (b, band index)
+  const int bi = (int)(band % p.units_per_img);
+  const int b = (int)(band / p.units_per_img);
+  const int ci = g * 64 + lane;
+
+  float acc[CO][K];
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) acc[c][kw] = 0.f;
+  float bsum[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bsum[c] = 0.f;
+
+  constexpr int CH = (64 / K) * K;  // pixels per dy fetch: a multiple of K keeps the rotation phase
+  const int oh_begin = bi * p.rows_per_unit, oh_end = min(p.Ho, oh_begin + p.rows_per_unit);
+  for (int oh = oh_begin; oh < oh_end; ++oh) {
+    const int ih = map_coord(oh - p.pad + kh, p.H, p.reflect);
+    const bool rowok = ih >= 0;
+    const float* rowp = p.x + ((long long)b * p.H + (rowok ? ih : 0)) * p.W * p.Cin + ci;
+    const float* dyrow = p.dy + ((long long)b * p.Ho + oh) * p.Wo * CO;
+    float win[K];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+      const int iw = map_coord(j - p.pad, p.W, p.reflect);
+      win[j] = (rowok && iw >= 0) ? rowp[(long long)iw * p.Cin] : 0.f;
+    }
+    for (int ow0 = 0; ow0 < p.Wo; ow0 += CH) {
+      const int n = min(CH, p.Wo - ow0);
+      float dyv[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) dyv[c] = (lane < n) ? dyrow[(long long)(ow0 + lane) * CO + c] : 0.f;
+#pragma unroll 1
+      for (int i0 = 0; i0 < n; i0 += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          const int i = i0 + s;  // pixels past n carry dy = 0 (lanes >= n loaded 0) and clamped loads
+          const int iw = map_coord(min(ow0 + i, p.Wo - 1) + (K - 1) - p.pad, p.W, p.reflect);
+          win[(K - 1 + s) % K] = (rowok && iw >= 0) ? rowp[(long long)iw * p.Cin] : 0.f;
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv[c]), i));
+            bsum[c] += d;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) acc[c][kw] = fmaf(d, win[(kw + s) % K], acc[c][kw]);
+          }
+        }
+      }
+    }
+  }
+  // slab row per (b, band): [CO][K][K][Cin] + CO bias sums; this wave owns [:, kh, :, 64g..64g+63]
+  const long long n_w = (long long)CO * K * K * p.Cin;
+  float* out = p.slab + band * (n_w + CO);
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) out[((long long)(c * K + kh) * K + kw) * p.Cin + ci] = acc[c][kw];
+  if (g == 0 && kh == 0 && lane < CO) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) v = (lane == c) ? bsum[c] : v;
+    out[n_w + lane] = v;
+  }
+}
+
+// dw = beta*dw + sum_r slab[r][0 : n_w]; db = beta*db + sum_r slab[r][n_w : n_w + CO]
+__global__ void small_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                         float* __restrict__ db, long long n_w, int co, long long rows,
+                                         float beta) {
+  const long long stride = n_w + co;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < stride;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long r = 0;
+    for (; r + 3 < rows; r += 4) {
+      s0 += slab[r * stride + i];
+      s1 += slab[(r + 1) * stride + i];
+      s2 += slab[(r + 2) * stride + i];
+      s3 += slab[(r + 3) * stride + i];
+    }
+    for (; r < rows; ++r) s0 += slab[r * stride + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < n_w) dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + s;
+    else if (db != nullptr) db[i - n_w] = (beta != 0.f ? beta * db[i - n_w] : 0.f) + s;
+  }
+}
+
+}  // namespace
+
+// ---- entry points used by the conv dispatch in conv_igemm.hip / conv_wgrad.hip (not part of the C ABI) ----
+bool munit_small_fwd_supported(const munit_conv_desc* d) {
+  return d->Cout == 3 && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->upsample == 0 && d->Cin % 16 == 0;
+}
+
+bool munit_small_wgrad_supported(const munit_conv_desc* d) {
+  return d->Cout == 3 && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->upsample == 0 && d->Cin % 64 == 0;
+}
+
+int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* w, const float* bias,
+                    float* y, hipStream_t st) {
+  SmallParams p{};
+  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo;
+  p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT; p.act = d->act; p.slope = d->slope;
+  p.tiles_x = cdiv(Wo, 64); p.tiles_y = cdiv(Ho, 4);
+  const long long blocks = (long long)d->B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 7>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  MUNIT_CHECK_LAUNCH("conv_patch_fwd");
+  return MUNIT_OK;
+}
+
+namespace {
+constexpr int WG_ROWS = 4;  // output rows per wgrad unit
+}
+
+size_t munit_small_wgrad_workspace(const munit_conv_desc* d, int Ho) {
+  const long long bands = (long long)d->B * cdiv(Ho, WG_ROWS);
+  return align_up((size_t)bands * ((size_t)3 * 49 * d->Cin + 3) * sizeof(float), 256);
+}
+
+int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* dy, float* dw,
+                      float* db, float beta, void* ws, hipStream_t st) {
+  SmallParams p{};
+  p.x = x; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo;
+  p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  p.rows_per_unit = WG_ROWS; p.units_per_img = cdiv(Ho, WG_ROWS);
+  const int G = d->Cin / 64;
+  const long long bands = (long long)d->B * p.units_per_img;
+  const long long units = bands * 7 * G;
+  hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  MUNIT_CHECK_LAUNCH("conv_lanes_wgrad");
+  const long long n_w = (long long)3 * 49 * d->Cin;
+  const int blocks = cdiv(n_w + 3, 256);
+  hipLaunchKernelGGL(small_slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, db, n_w, 3, bands, beta);
+  MUNIT_CHECK_LAUNCH("small_slab_reduce");
+  return MUNIT_OK;
+}

@@ -238,6 +238,7 @@ int plan_wgrad(const munit_conv_desc* d, WgradPlan* pl) {
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   WgradPlan pl;
   if (plan_wgrad(d, &pl)) return 0;
+  if (munit_small_wgrad_supported(d)) return munit_small_wgrad_workspace(d, pl.Ho);
   return pl.slab_bytes + pl.bias_bytes;
 }
 
@@ -248,6 +249,13 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   int rc = plan_wgrad(d, &pl);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+  if (munit_small_wgrad_supported(d)) {
+    if (ws_bytes < munit_small_wgrad_workspace(d, pl.Ho)) {
+      munit_set_error("conv2d_wgrad: workspace too small");
+      return MUNIT_ERR_WORKSPACE;
+    }
+    return munit_small_wgrad(d, pl.Ho, pl.Wo, x, dy, dw, db, beta, ws, (hipStream_t)stream);
+  }
   if (ws_bytes < pl.slab_bytes + pl.bias_bytes) {
     munit_set_error("conv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.slab_bytes + pl.bias_bytes);
     return MUNIT_ERR_WORKSPACE;

@@ -47,14 +47,12 @@ __device__ inline float apply_act(float v, int act, float slope) {
 // Map a coordinate of the padded (and optionally x2-upsampled) domain back to the source.
 // v is in upsampled-domain coordinates (may be out of range); returns source index or -1.
 __device__ inline int src_coord(int v, int Hu, int ups, int reflect) {
-  if (v < 0) {
-    if (!reflect) return -1;
-    v = -v;
-  } else if (v >= Hu) {
-    if (!reflect) return -1;
-    v = 2 * Hu - 2 - v;
-  }
-  return v >> ups;
+  // branch-free: reflect about the edges (|v| and 2Hu-2-v), or -1 outside in zero-pad mode
+  const bool inside = v >= 0 && v < Hu;
+  int r = v < 0 ? -v : v;
+  r = r >= Hu ? 2 * Hu - 2 - r : r;
+  r = reflect ? r : (inside ? v : -1);
+  return r < 0 ? -1 : (r >> ups);
 }
 
 // conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side

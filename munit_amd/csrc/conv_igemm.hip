@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   const int c4 = tid & 7;   // float4 column inside the 32-wide K tile
   const int r0 = tid >> 3;  // 0..31
   const int HoWo = p.Ho * p.Wo;
-  long long a_base[4];
+  int a_base[4];            // b*H*W (pixel index of the sample's first pixel)
   int a_ih0[4], a_iw0[4];
   bool a_ok[4];
   uint2 a_ch[4], a_cw[4];  // ROLE 2 only: packed fold candidates per axis
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     int rem = mm - b * HoWo;
     int oh = rem / p.Wo;
     int ow = rem - oh * p.Wo;
-    a_base[i] = (long long)b * p.H * p.W;
+    a_base[i] = b * p.H * p.W;
     a_ih0[i] = oh * p.stride - p.pad;
     a_iw0[i] = ow * p.stride - p.pad;
     if constexpr (ROLE == 2) {
@@ -140,64 +140,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   f32x4 rx[ROLE == 2 ? 4 : 1];  // ROLE 2: second folded contribution per row
   int kh = 0, kw = 0, c0 = 0;   // aligned-mode K iterator
   const int nk = (p.Ktot + BK - 1) / BK;
+  // aligned mode: float offset of channel 0 of the pixel each loader row reads for the CURRENT tap
+  // (-1 = contributes zero); recomputed only when the tap changes, i.e. every Cin/32 K-tiles
+  int aoff[4];
+  int aoff1[ROLE == 2 ? 4 : 1];
+
+  auto tap_setup = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (ROLE == 2) {
+        const int nw = a_nc[i] >> 4;
+        const int ncomb = (a_nc[i] & 15) * nw;
+        int o0 = -1, o1 = -1;
+        {
+          const int vh = cand_at(a_ch[i], 0) + kh - (p.KH - 1);
+          const int vw = cand_at(a_cw[i], 0) + kw - (p.KW - 1);
+          const bool ok = a_ok[i] && vh >= 0 && vh < p.H && vw >= 0 && vw < p.W;
+          o0 = ok ? (a_base[i] + vh * p.W + vw) * p.Cin : -1;
+        }
+        {
+          const int vh = cand_at(a_ch[i], nw >= 2 ? 0 : 1) + kh - (p.KH - 1);
+          const int vw = cand_at(a_cw[i], nw >= 2 ? 1 : 0) + kw - (p.KW - 1);
+          const bool ok = a_ok[i] && ncomb >= 2 && vh >= 0 && vh < p.H && vw >= 0 && vw < p.W;
+          o1 = ok ? (a_base[i] + vh * p.W + vw) * p.Cin : -1;
+        }
+        aoff[i] = o0;
+        aoff1[i] = o1;
+      } else {
+        const int ih = src_coord(a_ih0[i] + kh, p.Hu, p.ups, p.reflect);
+        const int iw = src_coord(a_iw0[i] + kw, p.Wu, p.ups, p.reflect);
+        const bool ok = a_ok[i] && ih >= 0 && iw >= 0;
+        aoff[i] = ok ? (a_base[i] + ih * p.W + iw) * p.Cin : -1;
+      }
+    }
+  };
 
   auto load_tile = [&](int kt) {
     if constexpr (ALIGNED) {
-      const int tap = kh * p.KW + kw;
+      if (c0 == 0) tap_setup();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (aoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(xg + (long long)aoff[i] + c0 + c4 * 4);
         if constexpr (ROLE == 2) {
           // Combination 0 (always) and 1 (border pixels / up-sampling) are plain predicated loads into
           // separate registers so they stay in flight behind the MFMAs; only pixels that fold more than
           // two padded positions (corners, up-sampling convs) take the dependent loop below.
           f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
-          const int nh = a_nc[i] & 15, nw = a_nc[i] >> 4;
-          const int ncomb = nh * nw;
-          if (a_ok[i]) {
-            {
-              const int vh = cand_at(a_ch[i], 0) + kh - (p.KH - 1);
-              const int vw = cand_at(a_cw[i], 0) + kw - (p.KW - 1);
+          if (aoff1[i] >= 0) x1 = *reinterpret_cast<const f32x4*>(xg + (long long)aoff1[i] + c0 + c4 * 4);
+          const int nw = a_nc[i] >> 4;
+          const int ncomb = (a_nc[i] & 15) * nw;
+          if (a_ok[i] && ncomb > 2) {
+            for (int cidx = 2; cidx < ncomb; ++cidx) {
+              const int a = cidx / nw, b2 = cidx - a * nw;
+              const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
+              const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
               if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
-                v = *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 + c4 * 4);
-            }
-            if (ncomb >= 2) {
-              const int vh = cand_at(a_ch[i], nw >= 2 ? 0 : 1) + kh - (p.KH - 1);
-              const int vw = cand_at(a_cw[i], nw >= 2 ? 1 : 0) + kw - (p.KW - 1);
-              if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
-                x1 = *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 + c4 * 4);
-            }
-            if (ncomb > 2) {
-              for (int cidx = 2; cidx < ncomb; ++cidx) {
-                const int a = cidx / nw, b2 = cidx - a * nw;
-                const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
-                const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
-                if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
-                  x1 += *reinterpret_cast<const f32x4*>(xg + (a_base[i] + (long long)vh * p.W + vw) * p.Cin + c0 +
-                                                        c4 * 4);
-              }
+                x1 += *reinterpret_cast<const f32x4*>(xg + (long long)(a_base[i] + vh * p.W + vw) * p.Cin + c0 + c4 * 4);
             }
           }
           rx[i] = x1;
-        } else {
-          int ih = src_coord(a_ih0[i] + kh, p.Hu, p.ups, p.reflect);
-          int iw = src_coord(a_iw0[i] + kw, p.Wu, p.ups, p.reflect);
-          bool ok = a_ok[i] && ih >= 0 && iw >= 0;
-          if (ok) {
-            const float* ptr = xg + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + c0 + c4 * 4;
-            v = *reinterpret_cast<const f32x4*>(ptr);
-          }
         }
         ra[i] = v;
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + 32 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.Cout) {
-          const float* ptr = wg + (long long)n * p.w_row + (long long)tap * p.Cin + c0 + c4 * 4;
-          v = *reinterpret_cast<const f32x4*>(ptr);
-        }
+        // k index is linear in the tile number: tap*Cin + c0 == kt*BK
+        if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(wg + (long long)n * p.w_row + kt * BK + c4 * 4);
         rb[i] = v;
       }
       c0 += BK;
@@ -484,6 +495,8 @@ int check_desc(const munit_conv_desc* d) {
     MUNIT_CHECK_ARG(d->pad < Hu && d->pad < Wu, "conv: reflect pad %d needs input > pad (got %dx%d)", d->pad, Hu, Wu);
   MUNIT_CHECK_ARG(Hu + 2 * d->pad >= d->KH && Wu + 2 * d->pad >= d->KW, "conv: kernel larger than padded input");
   MUNIT_CHECK_ARG((long long)d->B * Hu * Wu < (1ll << 31) / 4, "conv: too many pixels for 32-bit tile indices");
+  MUNIT_CHECK_ARG((long long)d->B * (Hu + 2 * d->pad) * (Wu + 2 * d->pad) * std::max(d->Cin, d->Cout) < (1ll << 31),
+                  "conv: tensor too large for the 32-bit element offsets of the tile loader");
   return MUNIT_OK;
 }
 

@@ -51,18 +51,25 @@ constexpr int LDS_LD = BK + 4;
 // Padded/up-sampled coordinates whose gradient folds onto source coordinate i (adjoint of
 // nearest x2 upsample followed by reflect/zero padding): up to 4, packed 16 bits each, 0xFFFF = none.
 __device__ inline uint2 fold_cands(int i, int Hu, int ups, int P, int reflect) {
-  unsigned c[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+  unsigned long long pk = ~0ull;  // four 16-bit slots, filled from the low end (no private array)
   int n = 0;
+  auto push = [&](int v) {
+    if (n < 4) {
+      const int sh = 16 * n;
+      pk = (pk & ~(0xFFFFull << sh)) | ((unsigned long long)(unsigned)v << sh);
+      ++n;
+    }
+  };
   const int nu = 1 << ups;
   for (int du = 0; du < nu; ++du) {
     const int hu = (i << ups) + du;
-    if (n < 4) c[n++] = (unsigned)(hu + P);
+    push(hu + P);
     if (reflect) {
-      if (hu >= 1 && hu <= P && n < 4) c[n++] = (unsigned)(P - hu);
-      if (hu >= Hu - 1 - P && hu <= Hu - 2 && n < 4) c[n++] = (unsigned)(2 * Hu - 2 - hu + P);
+      if (hu >= 1 && hu <= P) push(P - hu);
+      if (hu >= Hu - 1 - P && hu <= Hu - 2) push(2 * Hu - 2 - hu + P);
     }
   }
-  return make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+  return make_uint2((unsigned)(pk & 0xFFFFFFFFull), (unsigned)(pk >> 32));
 }
 __device__ inline int cand_at(uint2 v, int a) {
   const unsigned w = (a & 2) ? v.y : v.x;
@@ -80,8 +87,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   constexpr int NT = BN / 64;       // 32-wide MFMA tiles along N per wave
   constexpr int WN = BN / 2;        // N extent per wave
   constexpr int BROWS = BN / 32;    // weight rows per loader thread
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  // double-buffered A/B tiles: one barrier per K-tile (72 KiB at BN=128: two blocks per CU)
+  __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDS_LD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -259,15 +267,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float* Ad = As + buf * (BM * LDS_LD);
+    float* Bd = Bs + buf * (BN * LDS_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (ROLE == 2) ra[i] += rx[i];
-      *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Ad[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+      *reinterpret_cast<f32x4*>(&Bd[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
   };
 
   f32x16 acc[2][NT];
@@ -278,23 +288,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
+  // two of the four 8-wide k groups of a K-tile: 2 x (2 + NT) ds_read_b128, 8 * 2 * NT MFMAs
+  auto compute_half = [&](int buf, int kq0) {
+    const float* Ac = As + buf * (BM * LDS_LD);
+    const float* Bc = Bs + buf * (BN * LDS_LD);
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
+    for (int kq = kq0; kq < kq0 + 2; ++kq) {
       f32x4 a[2], b[NT];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 64 + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        b[nt] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + nt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+        b[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -303,11 +311,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
     }
-    __syncthreads();
+  };
+
+  // Pipeline: while tile t is multiplied out of LDS buffer t&1, the registers hold tile t+1 (loads issued
+  // during tile t-1); half-way through the MFMAs they are written to the other buffer -- safe, every wave
+  // passed the barrier that ended tile t-1 and nobody reads that buffer before the next barrier -- and the
+  // loads of tile t+2 are issued into the freed registers.  One barrier per K-tile.
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  if (nk > 1) load_tile(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    compute_half(cur, 0);
     if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
+      store_tile(cur ^ 1);
+      if (kt + 2 < nk) load_tile(kt + 2);
     }
+    compute_half(cur, 2);
+    __syncthreads();
   }
 
   // ---- epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave) ----

@@ -79,17 +79,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 
   f32x4 rx[4], rd[DROWS];
 
+  // pixel coordinates of this thread's 4 gather rows, advanced incrementally by 32 pixels per step
+  // (one division per row up front instead of two per row per step)
+  int px_oh[4], px_ow[4], px_base[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m_begin + xr0 + 8 * i;
+    int mm = m < p.M ? m : 0;
+    int b = mm / HoWo;
+    int rem = mm - b * HoWo;
+    px_oh[i] = rem / p.Wo;
+    px_ow[i] = rem - px_oh[i] * p.Wo;
+    px_base[i] = b * p.H * p.W;
+  }
+
   auto load_tiles = [&](int mbase) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int m = mbase + xr0 + 8 * i;
-      bool mok = m < m_end;
-      int mm = mok ? m : 0;
-      int b = mm / HoWo;
-      int rem = mm - b * HoWo;
-      int oh = rem / p.Wo;
-      int ow = rem - oh * p.Wo;
-      long long base = (long long)b * p.H * p.W;
+      const int m = mbase + xr0 + 8 * i;
+      const bool mok = m < m_end;
+      const int oh = px_oh[i], ow = px_ow[i];
+      const long long base = px_base[i];
+      // advance to the pixel of the next step
+      if (p.Wo >= WP) {  // wave-uniform: at most one row wrap per step, done with selects
+        int w = px_ow[i] + WP;
+        const bool wrap = w >= p.Wo;
+        w -= wrap ? p.Wo : 0;
+        int h = px_oh[i] + (wrap ? 1 : 0);
+        const bool wrap2 = h >= p.Ho;
+        px_ow[i] = w;
+        px_oh[i] = wrap2 ? 0 : h;
+        px_base[i] += wrap2 ? p.H * p.W : 0;
+      } else {
+        px_ow[i] += WP;
+        while (px_ow[i] >= p.Wo) {
+          px_ow[i] -= p.Wo;
+          if (++px_oh[i] == p.Ho) { px_oh[i] = 0; px_base[i] += p.H * p.W; }
+        }
+      }
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if constexpr (ALIGNED) {
@@ -194,15 +221,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   if (do_bias && tid < BC && co0 + tid < p.Cout) p.bias_slab[(long long)split * p.Cout + co0 + tid] = bsum;
 }
 
-// dst[i] = beta*dst[i] + sum_s slab[s][i]
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, long long n,
+// dw[i] = beta*dw[i] + sum_s slab[s][i] (i < n) and, in the same launch, db[j] likewise from bias_slab
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
+                                   const float* __restrict__ bias_slab, float* __restrict__ db, int nb,
                                    int nsplit, float beta) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  const long long total = n + (db != nullptr ? nb : 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * n + i];
-    dst[i] = (beta != 0.f ? beta * dst[i] : 0.f) + s;
+    if (i < n) {
+      for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * n + i];
+      dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + s;
+    } else {
+      const long long j = i - n;
+      for (int k = 0; k < nsplit; ++k) s += bias_slab[(long long)k * nb + j];
+      db[j] = (beta != 0.f ? beta * db[j] : 0.f) + s;
+    }
   }
+}
+
+// resident 256-thread blocks per CU of each instantiation (occupancy query, cached; 3 when unknown)
+int wgrad_blocks_per_cu(int bc, bool aligned) {
+  static int cache[2][2] = {{0, 0}, {0, 0}};
+  int& c = cache[bc == 128][aligned];
+  if (c == 0) {
+    int n = 0;
+    hipError_t e;
+    if (bc == 128) {
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, true>, 256, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, false>, 256, 0);
+    } else {
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, true>, 256, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, false>, 256, 0);
+    }
+    if (e != hipSuccess) (void)hipGetLastError();  // e.g. no device in the build container
+    c = (e == hipSuccess && n > 0) ? std::min(n, 8) : 3;
+  }
+  return c;
 }
 
 struct WgradPlan {
@@ -219,8 +274,12 @@ int plan_wgrad(const munit_conv_desc* d, WgradPlan* pl) {
   pl->k_tiles = cdiv(pl->Ktot, WK);
   pl->c_tiles = cdiv(d->Cout, pl->bc);
   const int tiles = pl->k_tiles * pl->c_tiles;
-  // aim for ~1024 blocks, at least 128 pixels per split, at most 512 splits
-  int want = cdiv(1024, tiles);
+  // One full round of resident blocks: 256 CUs x blocks/CU the register budget admits.  A grid of e.g.
+  // 1025 equal blocks on 1024 slots costs two rounds, so the split count is floored to fit one round;
+  // at least 128 pixels per split, at most 512 splits.
+  const int per_cu = wgrad_blocks_per_cu(pl->bc, d->Cin % 4 == 0);
+  const int slots = 256 * per_cu;
+  int want = std::max(1, slots / tiles);
   int max_by_pix = std::max(1, pl->M / 128);
   int ns = std::max(1, std::min(std::min(want, max_by_pix), 512));
   int pps = cdiv(pl->M, ns);
@@ -283,15 +342,10 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   MUNIT_CHECK_LAUNCH("conv_wgrad");
   {
     long long n = (long long)d->Cout * pl.Ktot;
-    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, n, pl.nsplit, beta);
-    MUNIT_CHECK_LAUNCH("slab_reduce(dw)");
-  }
-  if (db) {
-    int blocks = cdiv(d->Cout, 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.bias_slab, db,
-                       (long long)d->Cout, pl.nsplit, beta);
-    MUNIT_CHECK_LAUNCH("slab_reduce(db)");
+    int blocks = (int)std::min<long long>((n + d->Cout + 255) / 256, 4096);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, n, p.bias_slab, db,
+                       d->Cout, pl.nsplit, beta);
+    MUNIT_CHECK_LAUNCH("slab_reduce");
   }
   return MUNIT_OK;
 }

@@ -459,18 +459,23 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
   }
 }
 
-// dgamma[c] = acc*dgamma[c] + sum_{b,split} cpart[..][0][c]; dbeta likewise with [1]
-__global__ void ln_bwd_param_kernel(const double* __restrict__ cpart, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int C, int nblk, float acc) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma[c] = acc*dgamma[c] + sum_{b,split} cpart[..][0][c]; dbeta likewise with [1].  One block per
+// channel, threads stride over the (sample, split) partial rows.
+__global__ __launch_bounds__(NT) void ln_bwd_param_kernel(const double* __restrict__ cpart, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int C, int nblk, float acc) {
+  __shared__ double red[NT / 64];
+  const int c = blockIdx.x;
   double g = 0.0, bt = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += NT) {
     g += cpart[((long long)k * 2) * C + c];
     bt += cpart[((long long)k * 2 + 1) * C + c];
   }
-  dgamma[c] = (acc != 0.f ? acc * dgamma[c] : 0.f) + (float)g;
-  dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + (float)bt;
+  g = block_sum(g, red);
+  bt = block_sum(bt, red);
+  if (threadIdx.x == 0) {
+    dgamma[c] = (acc != 0.f ? acc * dgamma[c] : 0.f) + (float)g;
+    dbeta[c] = (acc != 0.f ? acc * dbeta[c] : 0.f) + (float)bt;
+  }
 }
 
 }  // namespace
@@ -572,7 +577,7 @@ extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float*
   hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(ns, B), dim3(NT), 0, st, x, dy, stats, spart, dx, HW, C, ns, gamma,
                      beta, relu, eps);
   MUNIT_CHECK_LAUNCH("ln_bwd_apply");
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, cpart, dgamma, dbeta, C, B * ns,
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(C), dim3(NT), 0, st, cpart, dgamma, dbeta, C, B * ns,
                      acc);
   MUNIT_CHECK_LAUNCH("ln_bwd_param");
   return MUNIT_OK;

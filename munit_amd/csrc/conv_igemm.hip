@@ -46,6 +46,7 @@ struct IgemmParams {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
+constexpr int NTHR = 512;
 constexpr int LDS_LD = BK + 4;
 
 // Padded/up-sampled coordinates whose gradient folds onto source coordinate i (adjoint of
@@ -83,10 +84,17 @@ __device__ inline int cand_at(uint2 v, int a) {
 // before the MFMA -- exact, because the GEMM is linear in A -- which removes the padded-domain
 // buffer and, for the up-sampling convs, 4x of the MFMA work).
 template <int BN, bool ALIGNED, int ROLE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
-  constexpr int NT = BN / 64;       // 32-wide MFMA tiles along N per wave
-  constexpr int WN = BN / 2;        // N extent per wave
-  constexpr int BROWS = BN / 32;    // weight rows per loader thread
+__global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
+  // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
+  // waves gather (measured MfmaUtil 73 % with 4 waves / 210 registers -> see profiles/).
+  constexpr int WAVES_N = BN / 32;            // 4 (BN=128) or 2 (BN=64): every wave owns 32 output channels
+  constexpr int WAVES_M = 8 / WAVES_N;        // 2 or 4
+  constexpr int WM = BM / WAVES_M;            // rows per wave: 64 or 32
+  constexpr int MT = WM / 32;                 // 32-row MFMA tiles per wave: 2 or 1
+  constexpr int NT = 1;
+  constexpr int WN = 32;
+  constexpr int AROWS = BM / 64;              // gather rows per loader thread (512 threads x float4 = 64 rows)
+  constexpr int BROWS = BN / 64;              // weight rows per loader thread
   // double-buffered A/B tiles: one barrier per K-tile (72 KiB at BN=128: two blocks per CU)
   __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDS_LD];
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int tile = blockIdx.x;
   const int n_tile = tile % p.n_tiles;
@@ -113,16 +121,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
 
   // ---- loader coordinates ----
   const int c4 = tid & 7;   // float4 column inside the 32-wide K tile
-  const int r0 = tid >> 3;  // 0..31
+  const int r0 = tid >> 3;  // 0..63
   const int HoWo = p.Ho * p.Wo;
-  int a_base[4];            // b*H*W (pixel index of the sample's first pixel)
-  int a_ih0[4], a_iw0[4];
-  bool a_ok[4];
-  uint2 a_ch[4], a_cw[4];  // ROLE 2 only: packed fold candidates per axis
-  int a_nc[4];             // ROLE 2 only: candidate counts (rows | cols << 4)
+  int a_base[AROWS];            // b*H*W (pixel index of the sample's first pixel)
+  int a_ih0[AROWS], a_iw0[AROWS];
+  bool a_ok[AROWS];
+  uint2 a_ch[AROWS], a_cw[AROWS];  // ROLE 2 only: packed fold candidates per axis
+  int a_nc[AROWS];                 // ROLE 2 only: candidate counts (rows | cols << 4)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + r0 + 32 * i;
+  for (int i = 0; i < AROWS; ++i) {
+    int m = m0 + r0 + 64 * i;
     a_ok[i] = m < p.M;
     int mm = a_ok[i] ? m : 0;
     int b = mm / HoWo;
@@ -144,18 +152,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     }
   }
 
-  f32x4 ra[4], rb[BROWS];
-  f32x4 rx[ROLE == 2 ? 4 : 1];  // ROLE 2: second folded contribution per row
+  f32x4 ra[AROWS], rb[BROWS];
+  f32x4 rx[ROLE == 2 ? AROWS : 1];  // ROLE 2: second folded contribution per row
   int kh = 0, kw = 0, c0 = 0;   // aligned-mode K iterator
   const int nk = (p.Ktot + BK - 1) / BK;
   // aligned mode: float offset of channel 0 of the pixel each loader row reads for the CURRENT tap
   // (-1 = contributes zero); recomputed only when the tap changes, i.e. every Cin/32 K-tiles
-  int aoff[4];
-  int aoff1[ROLE == 2 ? 4 : 1];
+  int aoff[AROWS];
+  int aoff1[ROLE == 2 ? AROWS : 1];
 
   auto tap_setup = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       if constexpr (ROLE == 2) {
         const int nw = a_nc[i] >> 4;
         const int ncomb = (a_nc[i] & 15) * nw;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     if constexpr (ALIGNED) {
       if (c0 == 0) tap_setup();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AROWS; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (aoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(xg + (long long)aoff[i] + c0 + c4 * 4);
         if constexpr (ROLE == 2) {
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + 64 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         // k index is linear in the tile number: tap*Cin + c0 == kt*BK
         if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(wg + (long long)n * p.w_row + kt * BK + c4 * 4);
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
         ekw[e] = tap - ekh[e] * p.KW;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AROWS; ++i) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        int n = n0 + r0 + 32 * i;
+        int n = n0 + r0 + 64 * i;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -271,18 +279,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     float* Ad = As + buf * (BM * LDS_LD);
     float* Bd = Bs + buf * (BN * LDS_LD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       if constexpr (ROLE == 2) ra[i] += rx[i];
-      *reinterpret_cast<f32x4*>(&Ad[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Ad[(r0 + 64 * i) * LDS_LD + c4 * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<f32x4*>(&Bd[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+      *reinterpret_cast<f32x4*>(&Bd[(r0 + 64 * i) * LDS_LD + c4 * 4]) = rb[i];
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -296,17 +304,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     const float* Bc = Bs + buf * (BN * LDS_LD);
 #pragma unroll
     for (int kq = kq0; kq < kq0 + 2; ++kq) {
-      f32x4 a[2], b[NT];
+      f32x4 a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 64 + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         b[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
@@ -339,10 +347,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     const bool n_ok = n < p.Cout;
     const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int row = wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int m = m0 + row;
         if (m < p.M && n_ok) {
           int b = m / HoWo;
@@ -487,7 +495,7 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
   q.n_tiles = cdiv(p.Cout, bn);
   const int m_tiles = cdiv(p.M, BM);
   dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
-  dim3 block(256);
+  dim3 block(NTHR);
   if constexpr (ROLE == 2) {
     if (!aligned) {
       munit_set_error("conv_igemm: folded backward-data needs Cout %% 32 == 0");

@@ -25,32 +25,42 @@ struct WgradParams {
   int pix_per_split;  // multiple of 32
 };
 
-constexpr int WK = 128;  // k columns per block
+
 constexpr int WP = 32;   // pixels per step
 
+constexpr int WTHR = 512;
+
 template <int BC, bool ALIGNED>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
-  constexpr int MT = BC / 64;  // 32-row MFMA tiles per wave along cout (wave grid 2x2)
-  constexpr int WC = BC / 2;
-  constexpr int DQ = BC / 4;   // float4 per dy row
-  constexpr int DROWS = WP * DQ / 256;  // dy rows per loader thread (4 for BC=128, 2 for 64)
-  __shared__ __attribute__((aligned(16))) float Ds[WP * BC];
-  __shared__ __attribute__((aligned(16))) float Xs[WP * WK];
+__global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
+  // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64), so every
+  // wave owns two 32x32 accumulators either way (2 cout tiles x 1 k tile, or 1 x 2).
+  constexpr int WKT = BC == 128 ? 128 : 256;
+  constexpr int NTK = WKT / 128;        // 32-col MFMA tiles per wave along k
+  constexpr int XQ = WKT / 4;           // float4 per gathered row
+  constexpr int XRPT = WTHR / XQ;       // gather rows covered per pass of the block: 16 or 8
+  constexpr int XROWS = WP / XRPT;      // gather rows per loader thread: 2 or 4
+  constexpr int WC = BC / 2;            // cout rows per wave
+  constexpr int MT = WC / 32;           // 32-row MFMA tiles per wave along cout: 2 (BC=128) or 1
+  constexpr int DQ = BC / 4;            // float4 per dy row
+  constexpr int DRPT = WTHR / DQ;       // dy rows covered per pass of the block: 16 or 32
+  constexpr int DROWS = WP / DRPT;      // dy rows per loader thread: 2 or 1
+  __shared__ __attribute__((aligned(16))) float Ds[2 * WP * BC];   // double-buffered: one barrier per step
+  __shared__ __attribute__((aligned(16))) float Xs[2 * WP * WKT];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int kc0 = blockIdx.x * WK;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int kc0 = blockIdx.x * WKT;
   const int co0 = blockIdx.y * BC;
   const int split = blockIdx.z;
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(p.M, m_begin + p.pix_per_split);
   const int HoWo = p.Ho * p.Wo;
 
-  // X-tile loader: 32 pixels x 128 k columns = 32 float4 per row; thread -> (row = tid>>5 + 8i, q = tid&31)
-  const int xq = tid & 31;
-  const int xr0 = tid >> 5;
+  // X-tile loader: 32 pixels x WKT k columns; thread -> (row = tid / XQ + XRPT*i, q = tid % XQ)
+  const int xq = tid % XQ;
+  const int xr0 = tid / XQ;
   int ekh[4], ekw[4], eci[4];
   bool eok[4];
   if constexpr (ALIGNED) {
@@ -73,18 +83,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       ekw[e] = tap - ekh[e] * p.KW;
     }
   }
-  // dy-tile loader: thread -> (row = tid / DQ + (256/DQ) * i, q = tid % DQ)
+  // dy-tile loader: thread -> (row = tid / DQ + DRPT * i, q = tid % DQ)
   const int dq = tid % DQ;
   const int dr0 = tid / DQ;
 
-  f32x4 rx[4], rd[DROWS];
+  f32x4 rx[XROWS], rd[DROWS];
 
-  // pixel coordinates of this thread's 4 gather rows, advanced incrementally by 32 pixels per step
+  // pixel coordinates of this thread's gather rows, advanced incrementally by 32 pixels per step
   // (one division per row up front instead of two per row per step)
-  int px_oh[4], px_ow[4], px_base[4];
+  int px_oh[XROWS], px_ow[XROWS], px_base[XROWS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m_begin + xr0 + 8 * i;
+  for (int i = 0; i < XROWS; ++i) {
+    int m = m_begin + xr0 + XRPT * i;
     int mm = m < p.M ? m : 0;
     int b = mm / HoWo;
     int rem = mm - b * HoWo;
@@ -95,8 +105,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 
   auto load_tiles = [&](int mbase) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mbase + xr0 + 8 * i;
+    for (int i = 0; i < XROWS; ++i) {
+      const int m = mbase + xr0 + XRPT * i;
       const bool mok = m < m_end;
       const int oh = px_oh[i], ow = px_ow[i];
       const long long base = px_base[i];
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 #pragma unroll
     for (int i = 0; i < DROWS; ++i) {
-      int m = mbase + dr0 + (256 / DQ) * i;
+      int m = mbase + dr0 + DRPT * i;
       int co = co0 + dq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < m_end) {
@@ -154,54 +164,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       rd[i] = v;
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    float* Xd = Xs + buf * (WP * WKT);
+    float* Dd = Ds + buf * (WP * BC);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Xs[(xr0 + 8 * i) * WK + xq * 4]) = rx[i];
+    for (int i = 0; i < XROWS; ++i) *reinterpret_cast<f32x4*>(&Xd[(xr0 + XRPT * i) * WKT + xq * 4]) = rx[i];
 #pragma unroll
-    for (int i = 0; i < DROWS; ++i)
-      *reinterpret_cast<f32x4*>(&Ds[(dr0 + (256 / DQ) * i) * BC + dq * 4]) = rd[i];
+    for (int i = 0; i < DROWS; ++i) *reinterpret_cast<f32x4*>(&Dd[(dr0 + DRPT * i) * BC + dq * 4]) = rd[i];
   };
 
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][NTK];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int t = 0; t < NTK; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
   float bsum = 0.f;  // bias column sum: thread tid < BC owns channel co0 + tid
   const bool do_bias = p.bias_slab != nullptr && blockIdx.x == 0;
 
-  if (m_begin < m_end) {
-    load_tiles(m_begin);
-    store_tiles();
-  }
-  __syncthreads();
   const int fr = lane & 31;
   const int fk = lane >> 5;
+  auto compute_half = [&](int buf, int k0) {
+    const float* Dc = Ds + buf * (WP * BC);
+    const float* Xc = Xs + buf * (WP * WKT);
+#pragma unroll
+    for (int kk = k0; kk < k0 + WP / 2; kk += 2) {
+      float a[MT], b[NTK];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[t] = Dc[(kk + fk) * BC + wm * WC + t * 32 + fr];
+#pragma unroll
+      for (int t = 0; t < NTK; ++t) b[t] = Xc[(kk + fk) * WKT + wn * (32 * NTK) + t * 32 + fr];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NTK; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+    }
+  };
+
+  // same pipeline as conv_igemm_kernel: registers hold step s+1 while step s is multiplied out of LDS
+  // buffer s&1; half-way they are written to the other buffer and the loads of step s+2 are issued.
+  if (m_begin < m_end) {
+    load_tiles(m_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  if (m_begin + WP < m_end) load_tiles(m_begin + WP);
+  int cur = 0;
   for (int mb = m_begin; mb < m_end; mb += WP) {
-    const bool more = mb + WP < m_end;
-    if (more) load_tiles(mb + WP);
-#pragma unroll
-    for (int kk = 0; kk < WP; kk += 2) {
-      float a[MT], b[2];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) a[t] = Ds[(kk + fk) * BC + wm * WC + t * 32 + fr];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) b[t] = Xs[(kk + fk) * WK + wn * 64 + t * 32 + fr];
-#pragma unroll
-      for (int s = 0; s < MT; ++s)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[s][t], 0, 0, 0);
+    compute_half(cur, 0);
+    if (mb + WP < m_end) {
+      store_tiles(cur ^ 1);
+      if (mb + 2 * WP < m_end) load_tiles(mb + 2 * WP);
     }
+    compute_half(cur, WP / 2);
     if (do_bias && tid < BC) {
+      const float* Dc = Ds + cur * (WP * BC);
 #pragma unroll 8
-      for (int r = 0; r < WP; ++r) bsum += Ds[r * BC + tid];
+      for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + tid];
     }
     __syncthreads();
-    if (more) store_tiles();
-    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- write the partial tile: slab[split][co][k] ----
@@ -209,12 +233,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = kc0 + wn * 64 + t * 32 + (lane & 31);
+    for (int u = 0; u < NTK; ++u) {
+      const int k = kc0 + wn * (32 * NTK) + u * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int co = co0 + wm * WC + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[s][t][r];
+        if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[s][u][r];
       }
     }
   }
@@ -240,7 +264,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
-// resident 256-thread blocks per CU of each instantiation (occupancy query, cached; 3 when unknown)
+// resident 512-thread blocks per CU of each instantiation (occupancy query, cached; 2 when unknown)
 int wgrad_blocks_per_cu(int bc, bool aligned) {
   static int cache[2][2] = {{0, 0}, {0, 0}};
   int& c = cache[bc == 128][aligned];
@@ -248,14 +272,14 @@ int wgrad_blocks_per_cu(int bc, bool aligned) {
     int n = 0;
     hipError_t e;
     if (bc == 128) {
-      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, true>, 256, 0);
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, false>, 256, 0);
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, true>, WTHR, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, false>, WTHR, 0);
     } else {
-      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, true>, 256, 0);
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, false>, 256, 0);
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, true>, WTHR, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, false>, WTHR, 0);
     }
     if (e != hipSuccess) (void)hipGetLastError();  // e.g. no device in the build container
-    c = (e == hipSuccess && n > 0) ? std::min(n, 8) : 3;
+    c = (e == hipSuccess && n > 0) ? std::min(n, 8) : 2;
   }
   return c;
 }
@@ -271,7 +295,7 @@ int plan_wgrad(const munit_conv_desc* d, WgradPlan* pl) {
   pl->M = d->B * pl->Ho * pl->Wo;
   pl->Ktot = d->KH * d->KW * d->Cin;
   pl->bc = d->Cout <= 64 ? 64 : 128;
-  pl->k_tiles = cdiv(pl->Ktot, WK);
+  pl->k_tiles = cdiv(pl->Ktot, pl->bc == 128 ? 128 : 256);
   pl->c_tiles = cdiv(d->Cout, pl->bc);
   const int tiles = pl->k_tiles * pl->c_tiles;
   // One full round of resident blocks: 256 CUs x blocks/CU the register budget admits.  A grid of e.g.
@@ -333,11 +357,11 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   const bool aligned = d->Cin % 4 == 0;
   dim3 grid((unsigned)pl.k_tiles, (unsigned)pl.c_tiles, (unsigned)pl.nsplit);
   if (pl.bc == 64) {
-    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(256), 0, st, p);
+    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(WTHR), 0, st, p);
   } else {
-    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(256), 0, st, p);
+    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(WTHR), 0, st, p);
   }
   MUNIT_CHECK_LAUNCH("conv_wgrad");
   {

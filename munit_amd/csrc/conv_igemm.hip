@@ -13,6 +13,7 @@
 // conflict-free ds_read_b128 for the MFMA operand fetch: one b128 feeds 4 MFMA k-steps).
 // Global loads for tile k+1 are issued before the MFMAs of tile k (register prefetch).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -104,7 +105,14 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  const int tile = blockIdx.x;
+  // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD one
+  // contiguous run of tiles; the n-tiles of an m-tile and vertically adjacent m-tiles (shared halo rows)
+  // then hit the same L2.  Pure speed heuristic -- any placement computes the same result.
+  int tile = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int n_tile = tile % p.n_tiles;
   const int m_tile = tile / p.n_tiles;
   const int m0 = m_tile * BM;
@@ -546,7 +554,8 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
   int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
-  if (munit_small_fwd_supported(d)) return munit_small_fwd(d, Ho, Wo, x, w, bias, y, (hipStream_t)stream);
+  if (munit_small_fwd_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_FWD"))
+    return munit_small_fwd(d, Ho, Wo, x, w, bias, y, (hipStream_t)stream);
   IgemmParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
@@ -612,8 +621,9 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     munit_conv_desc t{};
     t.B = d->B; t.H = pl->Ho; t.W = pl->Wo; t.Cin = d->Cout; t.Cout = d->Cin; t.KH = pl->TH; t.KW = pl->TW;
     t.stride = 1; t.pad = pl->TH - 1; t.pad_mode = MUNIT_PAD_ZERO;
-    pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t);
+    pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t) && !getenv("MUNIT_DEBUG_NO_SMALL_DGRAD");
     if (pl->small) pl->folded = false;
+    if (getenv("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
   }
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);

@@ -10,6 +10,7 @@
 // in LDS as [pixel][channel]; the MFMA operand fetch is one ds_read_b32 per lane
 // (lanes 0-31 = consecutive channels => conflict-free).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -321,7 +322,7 @@ int plan_wgrad(const munit_conv_desc* d, WgradPlan* pl) {
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   WgradPlan pl;
   if (plan_wgrad(d, &pl)) return 0;
-  if (munit_small_wgrad_supported(d)) return munit_small_wgrad_workspace(d, pl.Ho);
+  if (munit_small_wgrad_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, pl.Ho);
   return pl.slab_bytes + pl.bias_bytes;
 }
 
@@ -332,7 +333,7 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   int rc = plan_wgrad(d, &pl);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && dy && dw && ws, "conv2d_wgrad: null pointer");
-  if (munit_small_wgrad_supported(d)) {
+  if (munit_small_wgrad_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_WGRAD")) {
     if (ws_bytes < munit_small_wgrad_workspace(d, pl.Ho)) {
       munit_set_error("conv2d_wgrad: workspace too small");
       return MUNIT_ERR_WORKSPACE;

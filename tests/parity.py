@@ -29,36 +29,39 @@ class GradCheck:
     """Gradient tolerance of one iteration vs the fp64 oracle.  SURVEY.md section 8c proposes 1e-2
     normalised max error.  The kernels themselves are pinned much tighter (1e-4) by the op-level
     tests on identical inputs; at step level one more effect exists, measured on the box with
-    tools/diag_grad.py: a ReLU pre-activation within fp32 noise of 0 takes the other branch than in
-    fp64, which switches ONE element of an upstream gradient on or off.  It shows up as an isolated
-    error of a few 1e-2 of max|g| in one output-channel row of a weight gradient (plus, for an
-    AdaIN+ReLU layer, one row of the MLP's last fc.weight and one fc.bias element), and for the small
-    first-layer tensors (9408 weights fed by few pixels) as up to a few 1e-2 in relative L2.  A few
-    such elements per million exist in any fp32 implementation (torch's own CPU fp32 run shows the
-    same signature), and which ones flip changes with every reordering of a sum.  So the step-level
-    rule is: every tensor within 5e-2 relative L2 and 1e-1 normalised max (catches any wiring /
-    accumulation / loss-weight error, which are O(1)); at least 90 % of the tensors within the tight
-    bounds 5e-3 relative L2 and 1e-2 normalised max (torch-CPU fp32 vs fp64 measures 4e-4..1.5e-3)."""
+    tools/diag_grad.py and tools/diag_xab.py: a ReLU pre-activation within fp32 noise of 0 takes the
+    other branch than in fp64, which switches ONE element of an upstream gradient on or off.
+      * In a 16x16x256 resblock map it shows up as an isolated error of a few 1e-2 of max|g| in one
+        output-channel row of a weight gradient.
+      * In the last style-encoder layer (4x4x256 at the 64x64 test size) one flipped element is
+        1/4096 of the style gradient's energy, i.e. ~1.6e-2 relative L2, spread smoothly over its 46x46
+        receptive field of x_ab -- and therefore over every tensor upstream of x_ab (measured:
+        swapping only the summation order of the image-head conv, 1e-6 in x_ab, moves 40 % of the
+        tensors by 2.5e-2 while x_ba's side stays at 5e-4).
+    Which elements flip changes with any reordering of a sum, in any fp32 implementation (torch's
+    CPU fp32 run shows the same signature).  So the step-level rule is: every tensor within 5e-2
+    relative L2 and 1e-1 normalised max (wiring / accumulation / loss-weight errors are O(1)), and
+    the MEDIAN tensor within 2e-3 relative L2 (torch-CPU fp32 vs fp64 measures 4e-4..1.5e-3)."""
 
-    L2_TIGHT, MAX_TIGHT, L2_HARD, MAX_HARD = 5e-3, 1e-2, 5e-2, 1e-1
-    L2_TOL = L2_HARD
+    L2_MEDIAN, L2_HARD, MAX_HARD = 2e-3, 5e-2, 1e-1
 
     def __init__(self):
-        self.n, self.loose, self.worst_max, self.worst_l2 = 0, [], 0.0, 0.0
+        self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0
         self.kinks = self.loose
 
     def add(self, name, mine, ref, check=True):
         e, l2 = nerr(mine, ref), l2err(mine, ref)
         self.worst_max, self.worst_l2 = max(self.worst_max, e), max(self.worst_l2, l2)
-        self.n += 1
-        if e > self.MAX_TIGHT or l2 > self.L2_TIGHT:
+        self.l2s.append(l2)
+        if e > 1e-2 or l2 > 5e-3:
             self.loose.append((name, round(e, 5), round(l2, 5)))
         if check:
             assert l2 <= self.L2_HARD and e <= self.MAX_HARD, ("grad", name, e, l2)
 
     def finish(self, check=True):
+        self.median = sorted(self.l2s)[len(self.l2s) // 2] if self.l2s else 0.0
         if check:
-            assert len(self.loose) <= max(2, self.n // 10), ("too many loose tensors", self.loose)
+            assert self.median <= self.L2_MEDIAN, ("median grad l2", self.median, self.loose)
 
 
 def oracle_states(hp, dtype):

@@ -62,8 +62,9 @@ typedef struct {
 
 int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo);
 
+size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d); /* 0 for most layers */
 int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w, const float* bias,
-                     float* y, munit_stream_t stream);
+                     float* y, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* backward-data (autograd of the sites above): dx[B][H][W][Cin] from dy[B][Ho][Wo][Cout]
  * (dy is the gradient w.r.t. the PRE-activation output; use munit_act_bwd first when an

@@ -43,7 +43,35 @@ struct IgemmParams {
   // ROLE 2 (backward-data with the pad/upsample adjoint folded into the gather): geometry of the
   // forward conv whose input gradient is being formed
   int f_pad, f_ups, f_reflect, f_Hu, f_Wu;
+  // frame mode (sub-pixel up-sampling conv): GEMM rows enumerate only the 2-pixel border frame of the
+  // Ho x Wo output (rows 0,1,Ho-2,Ho-1 in full, then columns 0,1,Wo-2,Wo-1 of the remaining rows)
+  int frame;
 };
+
+// row index -> (sample, output row, output column)
+__device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, int& oh, int& ow) {
+  if (!frame) {
+    const int HoWo = Ho * Wo;
+    b = m / HoWo;
+    const int rem = m - b * HoWo;
+    oh = rem / Wo;
+    ow = rem - oh * Wo;
+  } else {
+    const int nb = 4 * Wo + 4 * (Ho - 4);
+    b = m / nb;
+    int r = m - b * nb;
+    if (r < 4 * Wo) {
+      const int q = r / Wo;
+      ow = r - q * Wo;
+      oh = q < 2 ? q : Ho - 4 + q;
+    } else {
+      r -= 4 * Wo;
+      const int q = r & 3;
+      oh = 2 + (r >> 2);
+      ow = q < 2 ? q : Wo - 4 + q;
+    }
+  }
+}
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -130,7 +158,6 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   // ---- loader coordinates ----
   const int c4 = tid & 7;   // float4 column inside the 32-wide K tile
   const int r0 = tid >> 3;  // 0..63
-  const int HoWo = p.Ho * p.Wo;
   int a_base[AROWS];            // b*H*W (pixel index of the sample's first pixel)
   int a_ih0[AROWS], a_iw0[AROWS];
   bool a_ok[AROWS];
@@ -141,10 +168,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
     int m = m0 + r0 + 64 * i;
     a_ok[i] = m < p.M;
     int mm = a_ok[i] ? m : 0;
-    int b = mm / HoWo;
-    int rem = mm - b * HoWo;
-    int oh = rem / p.Wo;
-    int ow = rem - oh * p.Wo;
+    int b, oh, ow;
+    decode_pixel(mm, p.Ho, p.Wo, p.frame, b, oh, ow);
     a_base[i] = b * p.H * p.W;
     a_ih0[i] = oh * p.stride - p.pad;
     a_iw0[i] = ow * p.stride - p.pad;
@@ -361,10 +386,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
         int row = wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         int m = m0 + row;
         if (m < p.M && n_ok) {
-          int b = m / HoWo;
-          int rem = m - b * HoWo;
-          int oh = rem / p.Wo;
-          int ow = rem - oh * p.Wo;
+          int b, oh, ow;
+          decode_pixel(m, p.Ho, p.Wo, p.frame, b, oh, ow);
           long long off = (long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n;
           yg[off] = apply_act(acc[mt][nt][r] + bv, p.act, p.slope);
         }
@@ -393,6 +416,34 @@ __global__ void wt_dgrad_kernel(const float* __restrict__ w, float* __restrict__
     int kh = pa + ps * (TH - 1 - t);
     int kw = pb + ps * (TW - 1 - r);
     wt[i] = w[(((long long)co * KH + kh) * KW + kw) * Cin + ci];
+  }
+}
+
+// Sub-pixel form of nearest-x2-upsample + 5x5 conv: output pixel (2i+a, 2j+b) reads source rows
+// i-1, i, i+1 with the 5 kernel rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (same for
+// columns), so each of the 4 phases is a 3x3 conv over the source with summed weights: 36 instead of
+// 100 MACs per source pixel and channel pair.  wc: [phase = a*2+b][Cout][3][3][Cin].
+__global__ void upw_combine_kernel(const float* __restrict__ w, float* __restrict__ wc, int Cout, int Cin) {
+  const long long per_phase = (long long)Cout * 9 * Cin;
+  const long long total = 4 * per_phase;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int dw = (int)(r % 3); r /= 3;
+    const int dh = (int)(r % 3); r /= 3;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int ph = (int)r;
+    const int a = ph >> 1, b = ph & 1;
+    // kernel rows merged into tap dh of phase a: first row and count
+    const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
+    const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
+    const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
+    const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
+    float s = 0.f;
+    for (int kh = h0; kh < h0 + hn; ++kh)
+      for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)co * 5 + kh) * 5 + kw) * Cin + ci];
+    wc[i] = s;
   }
 }
 
@@ -548,14 +599,30 @@ extern "C" int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo) {
   return MUNIT_OK;
 }
 
+namespace {
+// nearest-x2 upsample + 5x5 reflect-pad-2 stride-1 conv: eligible for the sub-pixel decomposition
+bool subpixel_ok(const munit_conv_desc* d) {
+  return d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
+         d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 32 == 0 && d->H >= 3 && d->W >= 3 &&
+         !getenv("MUNIT_DEBUG_NO_SUBPIXEL");
+}
+}  // namespace
+
+extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return subpixel_ok(d) ? align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256) : 0;
+}
+
 extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w,
-                                const float* bias, float* y, munit_stream_t stream) {
+                                const float* bias, float* y, void* ws, size_t ws_bytes,
+                                munit_stream_t stream) {
   int Ho, Wo;
   int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
   if (munit_small_fwd_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_FWD"))
-    return munit_small_fwd(d, Ho, Wo, x, w, bias, y, (hipStream_t)stream);
+    return munit_small_fwd(d, Ho, Wo, x, w, bias, y, st);
   IgemmParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
@@ -571,7 +638,41 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
   p.M = d->B * Ho * Wo;
   p.act = d->act; p.slope = d->slope;
   p.ps = 1;
-  return launch_igemm<0>(p, 1, (hipStream_t)stream);
+  if (subpixel_ok(d)) {
+    // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
+    // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
+    const size_t need = munit_conv2d_fwd_workspace_bytes(d);
+    if (ws == nullptr || ws_bytes < need) {
+      munit_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+      return MUNIT_ERR_WORKSPACE;
+    }
+    float* wc = reinterpret_cast<float*>(ws);
+    {
+      long long total = (long long)4 * 9 * d->Cout * d->Cin;
+      int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL(upw_combine_kernel, dim3(blocks), dim3(256), 0, st, w, wc, d->Cout, d->Cin);
+      MUNIT_CHECK_LAUNCH("upw_combine");
+    }
+    IgemmParams q = p;
+    q.w = wc;
+    q.ups = 0; q.Hu = d->H; q.Wu = d->W;
+    q.Ho = d->H; q.Wo = d->W;                 // one GEMM row per source pixel and phase
+    q.KH = 3; q.KW = 3; q.pad = 1; q.reflect = 0;
+    q.Ktot = 9 * d->Cin; q.w_row = q.Ktot;
+    q.y_sw = 2 * d->Cout;
+    q.y_sh = (long long)2 * Wo * d->Cout;
+    q.M = d->B * d->H * d->W;
+    q.ps = 2;
+    q.w_phase = (long long)d->Cout * q.Ktot;
+    q.y_phase_row = (long long)Wo * d->Cout;
+    q.y_phase_col = d->Cout;
+    rc = launch_igemm<0>(q, 4, st);
+    if (rc) return rc;
+    p.frame = 1;
+    p.M = d->B * (4 * Wo + 4 * (Ho - 4));
+    return launch_igemm<0>(p, 1, st);
+  }
+  return launch_igemm<0>(p, 1, st);
 }
 
 namespace {

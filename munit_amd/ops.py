@@ -98,13 +98,20 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
     d = _desc(x, weight, stride, pad, pad_type, upsample, act, slope)
     ho, wo = _out_hw(d)
     y = empty_nhwc(x.shape[0], weight.shape[0], ho, wo, x)
+    nbytes = lib.munit_conv2d_fwd_workspace_bytes(byref(d))
+    ws = workspace(nbytes, x.device) if nbytes else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.munit_conv2d_fwd(byref(d), _p(x), _p(weight), _p(bias), _p(y), _stream()), "conv2d_fwd")
+    _lib.check(lib.munit_conv2d_fwd(byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws),
+                                    ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
     if PROFILE is not None:
         e1.record()
         tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if d.Cout <= 64 else 128, "true" if d.Cin % 32 == 0 else "false")
+        if nbytes:
+            tag = "subpixel_upsample_conv"      # three kernels (weight merge, 4 phase convs, frame): not one launch
+        elif d.Cout <= 4:
+            tag = "conv_patch_fwd_kernel"
         PROFILE.append((tag, 2.0 * d.B * ho * wo * d.Cout * d.KH * d.KW * d.Cin, e0, e1))
     return y
 

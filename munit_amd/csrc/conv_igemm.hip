@@ -46,6 +46,10 @@ struct IgemmParams {
   // frame mode (sub-pixel up-sampling conv): GEMM rows enumerate only the 2-pixel border frame of the
   // Ho x Wo output (rows 0,1,Ho-2,Ho-1 in full, then columns 0,1,Wo-2,Wo-1 of the remaining rows)
   int frame;
+  // split-K (small grids): blockIdx.z = split, K-tiles [z*kt_per_split, ...); raw partial tiles go to
+  // slab[(phase*ksplit + z)][M][Cout] and splitk_epilogue_kernel sums them in order (+bias, act)
+  int ksplit, kt_per_split;
+  float* slab;
 };
 
 // row index -> (sample, output row, output column)
@@ -188,7 +192,17 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   f32x4 ra[AROWS], rb[BROWS];
   f32x4 rx[ROLE == 2 ? AROWS : 1];  // ROLE 2: second folded contribution per row
   int kh = 0, kw = 0, c0 = 0;   // aligned-mode K iterator
-  const int nk = (p.Ktot + BK - 1) / BK;
+  const int nk_total = (p.Ktot + BK - 1) / BK;
+  const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+  const int kt_end = p.ksplit > 1 ? min(nk_total, kt_begin + p.kt_per_split) : nk_total;
+  if constexpr (ALIGNED) {
+    if (kt_begin > 0) {
+      const int k0 = kt_begin * BK, tap = k0 / p.Cin;
+      c0 = k0 - tap * p.Cin;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
+  }
   // aligned mode: float offset of channel 0 of the pixel each loader row reads for the CURRENT tap
   // (-1 = contributes zero); recomputed only when the tap changes, i.e. every Cin/32 K-tiles
   int aoff[AROWS];
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
 
   auto load_tile = [&](int kt) {
     if constexpr (ALIGNED) {
-      if (c0 == 0) tap_setup();
+      if (c0 == 0 || kt == kt_begin) tap_setup();
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -358,21 +372,40 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   // during tile t-1); half-way through the MFMAs they are written to the other buffer -- safe, every wave
   // passed the barrier that ended tile t-1 and nobody reads that buffer before the next barrier -- and the
   // loads of tile t+2 are issued into the freed registers.  One barrier per K-tile.
-  load_tile(0);
-  store_tile(0);
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
   __syncthreads();
-  if (nk > 1) load_tile(1);
+  if (nk > 1) load_tile(kt_begin + 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     compute_half(cur, 0);
     if (kt + 1 < nk) {
       store_tile(cur ^ 1);
-      if (kt + 2 < nk) load_tile(kt + 2);
+      if (kt + 2 < nk) load_tile(kt_begin + kt + 2);
     }
     compute_half(cur, 2);
     __syncthreads();
   }
 
+  if (p.ksplit > 1) {
+    // raw partial tile -> slab[(phase*ksplit + split)][m][n]
+    float* sl = p.slab + ((long long)blockIdx.y * p.ksplit + blockIdx.z) * (long long)p.M * p.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * WN + nt * 32 + (lane & 31);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < p.M && n < p.Cout) sl[(long long)m * p.Cout + n] = acc[mt][nt][r];
+        }
+    }
+    return;
+  }
   // ---- epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave) ----
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -393,6 +426,26 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
         }
       }
     }
+  }
+}
+
+// y[pixel(m)][n] = act(sum_s slab[(phase*ksplit + s)][m][n] + bias[n])   (fixed summation order)
+__global__ void splitk_epilogue_kernel(IgemmParams p, int phases) {
+  const long long per = (long long)p.M * p.Cout;
+  const long long total = per * phases;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ph = (int)(i / per);
+    const long long r = i - (long long)ph * per;
+    const int m = (int)(r / p.Cout), n = (int)(r - (long long)m * p.Cout);
+    float s = 0.f;
+    for (int k = 0; k < p.ksplit; ++k) s += p.slab[((long long)ph * p.ksplit + k) * per + r];
+    int b, oh, ow;
+    decode_pixel(m, p.Ho, p.Wo, p.frame, b, oh, ow);
+    float* yg = p.y;
+    if (p.ps > 1) yg += (long long)(ph / p.ps) * p.y_phase_row + (long long)(ph % p.ps) * p.y_phase_col;
+    const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+    yg[(long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n] = apply_act(s + bv, p.act, p.slope);
   }
 }
 
@@ -546,14 +599,39 @@ __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restric
     y[i] += a[i];
 }
 
+// Split-K factor for grids that cannot fill the chip: a 128x128 tile with K = 4096 is 128 sequential
+// K-tiles (~150-290 us) however few blocks there are.  0 workspace -> no split.
+int pick_ksplit(int M, int Cout, int Ktot, int phases) {
+  const int bn = Cout <= 64 ? 64 : 128;
+  const int tiles = cdiv(M, BM) * cdiv(Cout, bn) * phases;
+  const int nk = cdiv(Ktot, BK);
+  if (tiles >= 192 || nk < 16 || getenv("MUNIT_DEBUG_NO_SPLITK")) return 1;
+  int ks = std::min(cdiv(512, tiles), nk / 4);
+  return std::max(1, std::min(ks, 32));
+}
+size_t splitk_bytes(int M, int Cout, int Ktot, int phases) {
+  const int ks = pick_ksplit(M, Cout, Ktot, phases);
+  return ks > 1 ? align_up((size_t)ks * phases * M * Cout * sizeof(float), 256) : 0;
+}
+
 template <int ROLE>
-int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
+int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = nullptr, size_t slab_bytes = 0) {
   const bool aligned = (p.Cin % BK == 0) && (p.w_row % 4 == 0);
   const int bn = p.Cout <= 64 ? 64 : 128;
   IgemmParams q = p;
   q.n_tiles = cdiv(p.Cout, bn);
   const int m_tiles = cdiv(p.M, BM);
-  dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
+  q.ksplit = 1;
+  if (slab != nullptr && ROLE != 2) {
+    const int ks = pick_ksplit(p.M, p.Cout, p.Ktot, phases);
+    if (ks > 1 && slab_bytes >= splitk_bytes(p.M, p.Cout, p.Ktot, phases)) {
+      const int nk = cdiv(p.Ktot, BK);
+      q.kt_per_split = cdiv(nk, ks);
+      q.ksplit = cdiv(nk, q.kt_per_split);
+      q.slab = reinterpret_cast<float*>(slab);
+    }
+  }
+  dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, (unsigned)q.ksplit);
   dim3 block(NTHR);
   if constexpr (ROLE == 2) {
     if (!aligned) {
@@ -570,6 +648,12 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st) {
     else hipLaunchKernelGGL((conv_igemm_kernel<128, false, ROLE>), grid, block, 0, st, q);
   }
   MUNIT_CHECK_LAUNCH("conv_igemm");
+  if (q.ksplit > 1) {
+    const long long total = (long long)p.M * p.Cout * phases;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, q, phases);
+    MUNIT_CHECK_LAUNCH("splitk_epilogue");
+  }
   return MUNIT_OK;
 }
 
@@ -609,8 +693,11 @@ bool subpixel_ok(const munit_conv_desc* d) {
 }  // namespace
 
 extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
-  if (check_desc(d)) return 0;
-  return subpixel_ok(d) ? align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256) : 0;
+  int Ho, Wo;
+  if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
+  if (subpixel_ok(d)) return align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256);
+  if (munit_small_fwd_supported(d)) return 0;
+  return splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
 }
 
 extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w,
@@ -672,7 +759,7 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
     p.M = d->B * (4 * Wo + 4 * (Ho - 4));
     return launch_igemm<0>(p, 1, st);
   }
-  return launch_igemm<0>(p, 1, st);
+  return launch_igemm<0>(p, 1, st, ws, ws_bytes);
 }
 
 namespace {
@@ -681,7 +768,7 @@ struct DgradPlan {
   bool direct;  // write dx directly (no pad / upsample / add): 1x1 convs, linear layers
   bool folded;  // stride-1, Cout % 32 == 0: pad/upsample adjoint folded into the gather (ROLE 2)
   bool small;   // 3 input channels, 7x7: padded-domain correlation on the thread-per-pixel VALU kernel
-  size_t wt_bytes, g_bytes;
+  size_t wt_bytes, g_bytes, sk_bytes;
 };
 // number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
 int max_fold_cands(int H, int ups, int P, int reflect) {
@@ -729,6 +816,9 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
+  pl->sk_bytes = (pl->folded || pl->small) ? 0
+                 : splitk_bytes(d->B * (pl->Ho + pl->TH - 1) * (pl->Wo + pl->TW - 1), d->Cin,
+                                pl->TH * pl->TW * d->Cout, pl->ps * pl->ps);
   return MUNIT_OK;
 }
 }  // namespace
@@ -736,7 +826,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
 extern "C" size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d) {
   DgradPlan pl;
   if (plan_dgrad(d, &pl)) return 0;
-  return pl.wt_bytes + pl.g_bytes;
+  return pl.wt_bytes + pl.g_bytes + pl.sk_bytes;
 }
 
 extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w,
@@ -746,8 +836,8 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
   int rc = plan_dgrad(d, &pl);
   if (rc) return rc;
   MUNIT_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
-  if (ws_bytes < pl.wt_bytes + pl.g_bytes) {
-    munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes);
+  if (ws_bytes < pl.wt_bytes + pl.g_bytes + pl.sk_bytes) {
+    munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes + pl.sk_bytes);
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -825,7 +915,7 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
   p.w_phase = (long long)d->Cin * p.Ktot;
   p.y_phase_row = (long long)pl.Wq * d->Cin;
   p.y_phase_col = d->Cin;
-  rc = launch_igemm<1>(p, pl.ps * pl.ps, st);
+  rc = launch_igemm<1>(p, pl.ps * pl.ps, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
   if (rc) return rc;
   if (!direct) {
     const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;

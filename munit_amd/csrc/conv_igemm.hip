@@ -254,12 +254,25 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
           const int nw = a_nc[i] >> 4;
           const int ncomb = (a_nc[i] & 15) * nw;
           if (a_ok[i] && ncomb > 2) {
-            for (int cidx = 2; cidx < ncomb; ++cidx) {
-              const int a = cidx / nw, b2 = cidx - a * nw;
-              const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
-              const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
-              if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
-                x1 += *reinterpret_cast<const f32x4*>(xg + (long long)(a_base[i] + vh * p.W + vw) * p.Cin + c0 + c4 * 4);
+            // remaining combinations two at a time: both loads are issued before either is consumed, so a
+            // corner pixel (4 combinations) pays one dependent round trip per K-tile, not two
+            for (int cidx = 2; cidx < ncomb; cidx += 2) {
+              f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+              {
+                const int a = cidx / nw, b2 = cidx - a * nw;
+                const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
+                const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
+                if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
+                  t0 = *reinterpret_cast<const f32x4*>(xg + (long long)(a_base[i] + vh * p.W + vw) * p.Cin + c0 + c4 * 4);
+              }
+              if (cidx + 1 < ncomb) {
+                const int a = (cidx + 1) / nw, b2 = cidx + 1 - a * nw;
+                const int vh = cand_at(a_ch[i], a) + kh - (p.KH - 1);
+                const int vw = cand_at(a_cw[i], b2) + kw - (p.KW - 1);
+                if (vh >= 0 && vh < p.H && vw >= 0 && vw < p.W)
+                  t1 = *reinterpret_cast<const f32x4*>(xg + (long long)(a_base[i] + vh * p.W + vw) * p.Cin + c0 + c4 * 4);
+              }
+              x1 += t0 + t1;
             }
           }
           rx[i] = x1;

@@ -109,7 +109,7 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
         e1.record()
         tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if d.Cout <= 64 else 128, "true" if d.Cin % 32 == 0 else "false")
         if nbytes:
-            tag = "subpixel_upsample_conv"      # three kernels (weight merge, 4 phase convs, frame): not one launch
+            tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
         elif d.Cout <= 4:
             tag = "conv_patch_fwd_kernel"
         PROFILE.append((tag, 2.0 * d.B * ho * wo * d.Cout * d.KH * d.KW * d.Cin, e0, e1))

@@ -158,6 +158,15 @@ int munit_weighted_sum(const float* const* terms, const float* w, int n, float* 
 int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
                     double beta2, double eps, double weight_decay, int step, munit_stream_t stream);
 
+/* ExtraAdam (scripts/extraadam.py:14-168; selected by `optimizer: extra...`, scripts/trainer.py:41-45,
+ * stepped by the *_opt_step methods, trainer.py:252-268: extrapolation on even iterations, step on odd).
+ * Every call advances the moments and forms u = -lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).
+ * mode 0: p_saved = p, p += u (first extrapolation since the last step); mode 1: p += u;
+ * mode 2: p = p_saved + u (the update step). */
+int munit_extraadam_step(float* p, const float* g, float* m, float* v, float* p_saved, size_t n, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, int step, int mode,
+                         munit_stream_t stream);
+
 /* y[i] = alpha * x[i] (+ y[i] if accumulate); used for the 1/world gradient averaging. */
 int munit_scale(const float* x, float* y, size_t n, float alpha, int accumulate, munit_stream_t stream);
 

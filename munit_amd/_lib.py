@@ -59,6 +59,8 @@ SIGNATURES = {
     "munit_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _P, _P]),
     "munit_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int,
                                 _P]),
+    "munit_extraadam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double,
+                                     c_double, c_int, c_int, _P]),
     "munit_scale": (c_int, [_P, _P, c_size_t, c_float, c_int, _P]),
 }
 

@@ -223,6 +223,25 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// ExtraAdam (scripts/extraadam.py:121-168 `update`, :30-84 extrapolation/step): both phases advance the
+// moments and return u = -lr*sqrt(bc2)/bc1 * m / (sqrt(v) + eps); mode 0: save p, p += u (first
+// extrapolation); mode 1: p += u (further extrapolations); mode 2: p = saved + u (the update step).
+__global__ void extraadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, float* __restrict__ pc, long long n, float step_size,
+                                 float beta1, float beta2, float eps, float wd, float omb1, float omb2, int mode) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float gr = g[i] + wd * pv;
+    const float mm = m[i] * beta1 + omb1 * gr;
+    const float vv = v[i] * beta2 + omb2 * gr * gr;
+    const float u = -step_size * mm / (sqrtf(vv) + eps);
+    m[i] = mm;
+    v[i] = vv;
+    if (mode == 0) pc[i] = pv;
+    p[i] = (mode == 2 ? pc[i] : pv) + u;
+  }
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float alpha, int acc) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     y[i] = alpha * x[i] + (acc ? y[i] : 0.f);
@@ -354,6 +373,20 @@ extern "C" int munit_adam_step(float* p, const float* g, float* m, float* v, siz
                      (long long)n, step_size, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc2_sqrt,
                      (float)(1.0 - beta1), (float)(1.0 - beta2));
   MUNIT_CHECK_LAUNCH("adam");
+  return MUNIT_OK;
+}
+
+extern "C" int munit_extraadam_step(float* p, const float* g, float* m, float* v, float* p_saved, size_t n, double lr,
+                                    double beta1, double beta2, double eps, double weight_decay, int step, int mode,
+                                    munit_stream_t stream) {
+  MUNIT_CHECK_ARG(p && g && m && v && p_saved && n > 0 && step >= 1 && mode >= 0 && mode <= 2, "extraadam_step: bad args");
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr * sqrt(bc2) / bc1);
+  hipLaunchKernelGGL(extraadam_kernel, dim3(grid_for((long long)n, 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
+                     p_saved, (long long)n, step_size, (float)beta1, (float)beta2, (float)eps, (float)weight_decay,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), mode);
+  MUNIT_CHECK_LAUNCH("extraadam");
   return MUNIT_OK;
 }
 

@@ -481,6 +481,15 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
                                    float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
+def extraadam_step(p, g, m, v, p_saved, lr, beta1, beta2, eps, weight_decay, step, mode):
+    lib = _lib.load()
+    for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq"), (p_saved, "saved params")):
+        _require(t, "extraadam " + nm)
+    _lib.check(lib.munit_extraadam_step(_p(p), _p(g), _p(m), _p(v), _p(p_saved), p.numel(), float(lr), float(beta1),
+                                        float(beta2), float(eps), float(weight_decay), int(step), int(mode),
+                                        _stream()), "extraadam_step")
+
+
 def scale_(x, alpha):
     lib = _lib.load()
     _require(x, "scale input")

@@ -118,6 +118,42 @@ class FusedAdam(Optimizer):
                     g[k] = val
 
 
+class FusedExtraAdam(FusedAdam):
+    """ExtraAdam (scripts/extraadam.py:14-168) on the flat buffers: `extrapolation()` saves the
+    parameters (first call since the last step), moves them by the Adam-style update and `step()`
+    applies the update computed at the extrapolated point to the saved parameters."""
+
+    def __init__(self, params, lr, betas, weight_decay, eps=1e-8):
+        super().__init__(params, lr, betas, weight_decay, eps)
+        self.flat_saved = None
+        self._has_copy = False
+
+    def bind(self, device):
+        old = self.flat_saved
+        super().bind(device)
+        self.flat_saved = torch.zeros_like(self.flat_p)
+        if old is not None and old.numel() == self.flat_saved.numel():
+            self.flat_saved.copy_(old)
+
+    def _update(self, mode):
+        g = self.param_groups[0]
+        self._step += 1
+        ops.extraadam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_saved, g["lr"],
+                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step, mode)
+
+    @torch.no_grad()
+    def extrapolation(self):
+        self._update(1 if self._has_copy else 0)
+        self._has_copy = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._has_copy:
+            raise RuntimeError("Need to call extrapolation before calling step.")
+        self._update(2)
+        self._has_copy = False
+
+
 class MUNIT_Trainer(nn.Module):
     def __init__(self, hyperparameters):
         super(MUNIT_Trainer, self).__init__()
@@ -133,9 +169,7 @@ class MUNIT_Trainer(nn.Module):
         self.hyperparameters = hyperparameters
         self.iterations = 0
 
-        if "extra" in hyperparameters["optimizer"]:
-            raise NotImplementedError("munit_amd: ExtraAdam (scripts/extraadam.py) is a later scope row "
-                                      "(SURVEY.md section 8f #1); use optimizer: adam")
+        optimizer = FusedExtraAdam if "extra" in hyperparameters["optimizer"] else FusedAdam  # trainer.py:41-45
         self.domain_classif_ab = hyperparameters.get("domain_adv_w", 0) > 0
         self.use_classifier_sr = hyperparameters["adaptation"]["dfeat_lambda"] > 0
         self.train_seg = hyperparameters["adaptation"]["sem_seg_lambda"] > 0
@@ -165,9 +199,9 @@ class MUNIT_Trainer(nn.Module):
             gen_params = list(self.gen_a.parameters()) + list(self.gen_b.parameters())
         else:
             gen_params = list(self.gen.parameters())
-        self.dis_opt = FusedAdam([p for p in dis_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
+        self.dis_opt = optimizer([p for p in dis_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
                                  weight_decay=hyperparameters["weight_decay"])
-        self.gen_opt = FusedAdam([p for p in gen_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
+        self.gen_opt = optimizer([p for p in gen_params if p.requires_grad], lr=lr, betas=(beta1, beta2),
                                  weight_decay=hyperparameters["weight_decay"])
         self.dis_scheduler = get_scheduler(self.dis_opt, hyperparameters)
         self.gen_scheduler = get_scheduler(self.gen_opt, hyperparameters)
@@ -221,10 +255,17 @@ class MUNIT_Trainer(nn.Module):
 
     # ---- optimizer steps (trainer.py:252-268) -----------------------------------------
     def dis_opt_step(self):
-        self.dis_opt.step()
+        """ExtraAdam extrapolates on even iterations and steps on odd ones (trainer.py:252-259)."""
+        if "extra" in self.hyperparameters["optimizer"] and (self.iterations % 2 == 0):
+            self.dis_opt.extrapolation()
+        else:
+            self.dis_opt.step()
 
     def gen_opt_step(self):
-        self.gen_opt.step()
+        if "extra" in self.hyperparameters["optimizer"] and (self.iterations % 2 == 0):
+            self.gen_opt.extrapolation()
+        else:
+            self.gen_opt.step()
 
     # ---- criteria (trainer.py:279-305) ------------------------------------------------
     def recon_criterion(self, input, target):

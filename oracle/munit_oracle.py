@@ -393,6 +393,53 @@ def adam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def extraadam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float,
+                     beta2: float, eps: float, wd: float) -> Tensor:
+    """ExtraAdam.update, extraadam.py:121-168 (amsgrad off): advances m, v in place and returns the
+    displacement u = -lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)."""
+    g = g + wd * p
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    step_size = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    return -step_size * m / (v.sqrt() + eps)
+
+
+class ExtraAdamState:
+    """Extragradient.extrapolation / .step, extraadam.py:30-84, over a list of tensors."""
+
+    def __init__(self, params, lr, betas, weight_decay, eps=1e-8):
+        self.params, self.lr, self.betas, self.wd, self.eps = params, lr, betas, weight_decay, eps
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.step_count = 0
+        self.copy = []
+
+    def _updates(self, grads, lr):
+        self.step_count += 1
+        return [None if g is None else
+                extraadam_update(p, g, m, v, self.step_count, lr, self.betas[0], self.betas[1], self.eps, self.wd)
+                for p, g, m, v in zip(self.params, grads, self.m, self.v)]
+
+    def extrapolation(self, grads, lr=None):
+        us = self._updates(grads, self.lr if lr is None else lr)
+        if not self.copy:
+            self.copy = [p.detach().clone() for p in self.params]
+        with torch.no_grad():
+            for p, u in zip(self.params, us):
+                if u is not None:
+                    p.add_(u)
+
+    def step(self, grads, lr=None):
+        if not self.copy:
+            raise RuntimeError("Need to call extrapolation before calling step.")
+        us = self._updates(grads, self.lr if lr is None else lr)
+        with torch.no_grad():
+            for p, c, u in zip(self.params, self.copy, us):
+                if u is not None:
+                    p.copy_(c + u)
+        self.copy = []
+
+
 def step_lr(base_lr: float, n_sched_steps: int, hp: dict) -> float:
     """get_scheduler, utils.py:1066-1090: StepLR(step_size, gamma); after n scheduler
     steps lr = base * gamma ** (n // step_size).  'constant' or absent -> base."""
@@ -421,6 +468,12 @@ class OracleTrainer:
                                  m=[torch.zeros_like(p) for p in params],
                                  v=[torch.zeros_like(p) for p in params])
         self.sched_steps = 0
+        self.iterations = 0
+        self.extra = "extra" in hp.get("optimizer", "adam")
+        if self.extra:
+            for grp in ("gen", "dis"):
+                self.opt[grp]["extra"] = ExtraAdamState(self.opt[grp]["params"], hp["lr"], (hp["beta1"], hp["beta2"]),
+                                                        hp["weight_decay"])
         self.losses: Dict[str, Tensor] = {}
 
     # trainer.py:1326-1335
@@ -440,6 +493,15 @@ class OracleTrainer:
 
     def _opt_step(self, grp: str, grads):
         o = self.opt[grp]
+        if self.extra:  # trainer.py:252-268: extrapolate on even iterations, step on odd ones
+            with torch.no_grad():
+                if self.iterations % 2 == 0:
+                    o["extra"].extrapolation(grads, self._lr())
+                else:
+                    o["extra"].step(grads, self._lr())
+            o["step"] = o["extra"].step_count
+            o["m"], o["v"] = o["extra"].m, o["extra"].v
+            return
         o["step"] += 1
         with torch.no_grad():
             for p, g, m, v in zip(o["params"], grads, o["m"], o["v"]):

@@ -109,7 +109,7 @@ def trainer_named_params(trainer):
 
 
 def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", oracle_dtype=torch.float64,
-                    step_size=2, check=True):
+                    step_size=2, check=True, optimizer="adam"):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
     losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end)."""
@@ -117,6 +117,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
 
     hp = O.default_hp(size, batch, gen_state)
     hp["step_size"] = step_size
+    hp["optimizer"] = optimizer
     gen, dis_a, dis_b = oracle_states(hp, oracle_dtype)
     orc = O.OracleTrainer(hp, gen, dis_a, dis_b)
     tr = MUNIT_Trainer(dict(hp))
@@ -141,6 +142,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
                 for (n, p), q in list(zip(gnames, o_gen)) + list(zip(dnames, o_dis)):
                     q.copy_(p.detach().to(oracle_dtype).cpu())
         gc = GradCheck()
+        tr.iterations = orc.iterations = it  # train.py:157,328: the caller owns the counter
         tr.update_learning_rate()
         orc.update_learning_rate()
         assert abs(tr.gen_opt.param_groups[0]["lr"] - orc._lr()) < 1e-15

@@ -114,10 +114,13 @@ def test_config_defaults_and_unsupported_losses(tmp_path):
     bad["semantic_w"] = 3
     with pytest.raises(NotImplementedError, match="semantic_w"):
         MUNIT_Trainer(bad)
-    bad = O.default_hp(64, 1, 1)
-    bad["optimizer"] = "extraadam"
-    with pytest.raises(NotImplementedError):
-        MUNIT_Trainer(bad)
+    xa = O.default_hp(64, 1, 1)
+    xa["optimizer"] = "extraadam"
+    tr = MUNIT_Trainer(xa)
+    assert type(tr.gen_opt).__name__ == "FusedExtraAdam"
+    tr.iterations = 1
+    with pytest.raises(RuntimeError, match="extrapolation"):
+        tr.gen_opt_step()                           # step before any extrapolation, as in the reference
 
 
 def test_lr_schedule_matches_reference_order():

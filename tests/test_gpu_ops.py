@@ -252,6 +252,25 @@ def test_adam_matches_torch_semantics():
     assert ep <= 2e-6 and em <= 1e-6 and ev <= 1e-6, (ep, em, ev)
 
 
+def test_extraadam_kernel_matches_oracle():
+    from munit_amd import ops
+    n = 777
+    p0 = rnd((n,), 1)
+    gs = [rnd((n,), 10 + k, 0.3) for k in range(5)]
+    pr = [p0.clone()]
+    st = O.ExtraAdamState(pr, 1e-3, (0.5, 0.999), 1e-4)
+    pd = p0.float().to(dev()).contiguous()
+    md, vd, sd = torch.zeros(n, device=dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    has_copy = False
+    for k, mode in enumerate(["extrapolation", "step", "extrapolation", "extrapolation", "step"]):
+        getattr(st, mode)([gs[k]])
+        code = 2 if mode == "step" else (1 if has_copy else 0)
+        has_copy = mode != "step"
+        ops.extraadam_step(pd, gs[k].float().to(dev()).contiguous(), md, vd, sd, 1e-3, 0.5, 0.999, 1e-8, 1e-4, k + 1, code)
+        assert float((pd.double().cpu() - pr[0]).abs().max()) <= 2e-6, (k, mode)
+    assert nerr(md, st.m[0]) <= 1e-6 and nerr(vd, st.v[0]) <= 1e-6
+
+
 def test_cpu_tensor_is_refused():
     """No CPU fallback: the product path must fail loudly off-device."""
     from munit_amd import ops

@@ -43,6 +43,13 @@ def test_step_matches_oracle(gs, iters):
     print(rep)
 
 
+def test_step_extraadam_matches_oracle():
+    """optimizer: extraadam: extrapolation on the even iteration, step on the
+    odd one, against the oracle whose ExtraAdam is pinned to the reference's scripts/extraadam.py."""
+    rep = run_step_parity(size=64, batch=1, gen_state=1, iters=2, device="cuda:0", optimizer="extraadam")
+    print(rep)
+
+
 def test_step_losses_match_golden(golden):
     """First-iteration losses straight against the fixture produced from the reference modules."""
     meta, _ = golden

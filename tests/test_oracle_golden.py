@@ -125,3 +125,19 @@ def test_step_matches_reference_sequence(golden, gs, iters):
             close_digest(dg(p), d_, 1e-9)
         for p, d_ in zip(tr.opt["dis"]["params"], rec["dis_after"]):
             close_digest(dg(p), d_, 1e-9)
+
+
+def test_extraadam_matches_reference_file():
+    """oracle ExtraAdamState vs the parameter trace produced by the reference's own
+    scripts/extraadam.py (tests/golden/make_golden_extraadam.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_extraadam.npz"))
+    p = [torch.from_numpy(g["p0"][:35].copy()).reshape(7, 5), torch.from_numpy(g["p0"][35:].copy())]
+    st = O.ExtraAdamState(p, 1e-3, (0.5, 0.999), 1e-4)
+    for k, mode in enumerate(g["modes"]):
+        grads = [torch.from_numpy(g["g"][k][:35].copy()).reshape(7, 5), torch.from_numpy(g["g"][k][35:].copy())]
+        getattr(st, str(mode))(grads)
+        got = np.concatenate([t.numpy().reshape(-1) for t in p])
+        assert np.abs(got - g["trace"][k]).max() <= 1e-14, (k, mode)
+    with pytest.raises(RuntimeError):
+        st.step([torch.zeros(7, 5, dtype=torch.float64), torch.zeros(11, dtype=torch.float64)])

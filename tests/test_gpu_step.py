@@ -114,3 +114,78 @@ def test_full_size_properties():
     m = y.double().mean(dim=(2, 3))
     v = (y.double() ** 2).mean(dim=(2, 3)) - m ** 2
     assert float(m.abs().max()) <= 1e-5 and float((v - 1).abs().max()) <= 1e-4
+
+
+def test_inference_forward_matches_oracle():
+    """MUNIT_Trainer.forward (trainer.py:307-334, SURVEY.md section 8f #2): translation with the fixed
+    display styles s_a / s_b, eval mode, batch = display_size."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(64, 2, 1)
+    hp["display_size"] = 2
+    gen, dis_a, dis_b = oracle_states(hp, torch.float64)
+    tr = MUNIT_Trainer(dict(hp))
+    load_into_trainer(tr, gen, dis_a, dis_b)
+    tr.to("cuda:0")
+    x_a, x_b, _, _ = O.synthetic_batch(2, 64, seed=3)
+    x_ab, x_ba = tr.forward(x_a.cuda(), x_b.cuda())
+    assert tr.training  # forward() restores train mode like the reference
+    view = O.GenView(gen, hp["gen"], True)
+    with torch.no_grad():
+        c_a, _ = view.encode(x_a.double(), 1)
+        c_b, _ = view.encode(x_b.double(), 2)
+        r_ba = view.decode(c_b, tr.s_a.double().cpu(), 1)
+        r_ab = view.decode(c_a, tr.s_b.double().cpu(), 2)
+    assert nerr(x_ab, r_ab) <= 1e-4 and nerr(x_ba, r_ba) <= 1e-4
+    outs = tr.sample(x_a.cuda(), x_b.cuda())
+    assert len(outs) == 8 and all(tuple(o.shape) == (2, 3, 64, 64) for o in outs)
+    assert nerr(outs[6], r_ba if hp["guided"] == 0 else outs[6]) == 0.0
+
+
+def test_checkpoint_roundtrip_on_device(tmp_path):
+    """save / resume (trainer.py:1337-1429, SURVEY.md section 8f #3) reproduce the next update bit for bit."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(64, 1, 1)
+    x_a, x_b, m_a, m_b = (t.cuda() for t in O.synthetic_batch(1, 64, seed=7))
+
+    def fresh():
+        torch.manual_seed(11)
+        t = MUNIT_Trainer(dict(hp))
+        t.to("cuda:0")
+        return t
+
+    a = fresh()
+    a.update_learning_rate(); a.dis_update(x_a, x_b, hp); a.gen_update(x_a, x_b, hp, m_a, m_b)
+    a.save(str(tmp_path), 0)
+    b = fresh()
+    assert b.resume(str(tmp_path), hp) == 1
+    for t in (a, b):
+        t.update_learning_rate(); t.dis_update(x_a, x_b, hp); t.gen_update(x_a, x_b, hp, m_a, m_b)
+    assert float(a.loss_gen_total) == float(b.loss_gen_total) and float(a.loss_dis_total) == float(b.loss_dis_total)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+
+
+def test_hd_config_shapes_run():
+    """BASELINE config #4 geometry (512x512, config_HD.yaml = same networks): encode/decode at full size vs
+    the oracle (batch 1), then one full update with finite losses."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = O.default_hp(512, 1, 1)
+    gen, dis_a, dis_b = oracle_states(hp, torch.float32)
+    tr = MUNIT_Trainer(dict(hp))
+    load_into_trainer(tr, gen, dis_a, dis_b)
+    tr.to("cuda:0")
+    x_a, x_b, m_a, m_b = O.synthetic_batch(1, 512, seed=7)
+    view = O.GenView(gen, hp["gen"], True)
+    with torch.no_grad():
+        c_ref, s_ref = view.encode(x_a, 1)
+        y_ref = view.decode(c_ref, s_ref, 2)
+        c, s = tr.gen.encode(x_a.cuda(), 1)
+        y = tr.gen.decode(c, s, 2)
+    assert tuple(c.shape) == (1, 256, 128, 128)
+    assert nerr(c, c_ref) <= 1e-4 and nerr(s, s_ref) <= 1e-4 and nerr(y, y_ref) <= 1e-4  # vs the fp32 oracle
+    tr.update_learning_rate()
+    tr.dis_update(x_a.cuda(), x_b.cuda(), hp)
+    tr.gen_update(x_a.cuda(), x_b.cuda(), hp, m_a.cuda(), m_b.cuda())
+    for k in ("loss_gen_total", "loss_dis_total"):
+        v = float(getattr(tr, k))
+        assert v == v and abs(v) < 1e4

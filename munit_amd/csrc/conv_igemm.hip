@@ -123,8 +123,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   constexpr int WAVES_N = BN / 32;            // 4 (BN=128) or 2 (BN=64): every wave owns 32 output channels
   constexpr int WAVES_M = 8 / WAVES_N;        // 2 or 4
   constexpr int WM = BM / WAVES_M;            // rows per wave: 64 or 32
-  constexpr int MT = WM / 32;                 // 32-row MFMA tiles per wave: 2 or 1
-  constexpr int NT = 1;
+  // v_mfma_f32_16x16x4_f32 tiles: measured on MI355X the 16x16x4 form sustains ~20 % more FLOP/s than
+  // 32x32x2 at the clocks the power manager grants under matrix load (tools/ubench/mfma_peak.hip); same
+  // LDS operand traffic per FLOP, same exact-f32 fma chain.
+  constexpr int MT = WM / 16;                 // 16-row MFMA tiles per wave: 4 or 2
+  constexpr int NT = 2;
   constexpr int WN = 32;
   constexpr int AROWS = BM / 64;              // gather rows per loader thread (512 threads x float4 = 64 rows)
   constexpr int BROWS = BN / 64;              // weight rows per loader thread
@@ -348,36 +351,43 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
       *reinterpret_cast<f32x4*>(&Bd[(r0 + 64 * i) * LDS_LD + c4 * 4]) = rb[i];
   };
 
-  f32x16 acc[MT][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
 
-  const int frag_row = lane & 31;
-  const int frag_k = (lane >> 5) * 4;
-  // two of the four 8-wide k groups of a K-tile: 2 x (2 + NT) ds_read_b128, 8 * 2 * NT MFMAs
-  auto compute_half = [&](int buf, int kq0) {
+  // 16x16x4 operand map: lane l holds A[row l&15][k = l>>4] / B[k = l>>4][col l&15].  Each lane reads
+  // four consecutive k of its row with one ds_read_b128 and uses element t in MFMA step t, i.e. step t
+  // contracts k = {4g + t : g = 0..3} of the 16-wide group -- a permutation of k, identical for A and B.
+  const int frag_row = lane & 15;
+  const int frag_k = (lane >> 4) * 4;
+  // one of the two 16-wide k groups of a K-tile: (MT + NT) ds_read_b128, 4 * MT * NT MFMAs
+  auto compute_half = [&](int buf, int kg) {
     const float* Ac = As + buf * (BM * LDS_LD);
     const float* Bc = Bs + buf * (BN * LDS_LD);
+    f32x4 a[MT], b[NT];
 #pragma unroll
-    for (int kq = kq0; kq < kq0 + 2; ++kq) {
-      f32x4 a[MT], b[NT];
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 16 + frag_row) * LDS_LD + kg * 16 + frag_k]);
+    // ROLE 2 carries two gather slots per row and has no registers to spare: it reads the A fragments in
+    // two batches (the scheduling fence keeps the compiler from hoisting the second batch over the MFMAs)
+    constexpr int MB = (ROLE == 2 && MT >= 4) ? MT / 2 : MT;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+    for (int m0t = 0; m0t < MT; m0t += MB) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        b[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 32 + frag_row) * LDS_LD + kq * 8 + frag_k]);
+      for (int mt = m0t; mt < m0t + MB; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16 + frag_row) * LDS_LD + kg * 16 + frag_k]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = m0t; mt < m0t + MB; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+      if constexpr (MB != MT) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -399,7 +409,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
       store_tile(cur ^ 1);
       if (kt + 2 < nk) load_tile(kt_begin + kt + 2);
     }
-    compute_half(cur, 2);
+    if constexpr (ROLE == 2) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads below the gather (registers)
+    compute_half(cur, 1);
     __syncthreads();
   }
 
@@ -408,28 +419,28 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
     float* sl = p.slab + ((long long)blockIdx.y * p.ksplit + blockIdx.z) * (long long)p.M * p.Cout;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wn * WN + nt * 32 + (lane & 31);
+      const int n = n0 + wn * WN + nt * 16 + (lane & 15);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * WM + mt * 16 + 4 * (lane >> 4) + r;   // C/D map: col = lane&15, row = 4*(lane>>4)+r
           if (m < p.M && n < p.Cout) sl[(long long)m * p.Cout + n] = acc[mt][nt][r];
         }
     }
     return;
   }
-  // ---- epilogue: bias + activation, NHWC store (32 consecutive channels per half-wave) ----
+  // ---- epilogue: bias + activation, NHWC store (16 consecutive channels per quarter-wave) ----
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + wn * WN + nt * 32 + (lane & 31);
+    const int n = n0 + wn * WN + nt * 16 + (lane & 15);
     const bool n_ok = n < p.Cout;
     const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int r = 0; r < 4; ++r) {
+        int row = wm * WM + mt * 16 + 4 * (lane >> 4) + r;
         int m = m0 + row;
         if (m < p.M && n_ok) {
           int b, oh, ow;

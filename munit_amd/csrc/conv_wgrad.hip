@@ -6,9 +6,9 @@
 // slab and slab_reduce_kernel sums them in a fixed order (deterministic, no atomics).
 // The bias gradient (column sums of dy) rides along in the k-tile-0 blocks.
 //
-// Tile: BC (cout) x 128 (k) accumulators, 32 pixels per step.  dy and A tiles are staged
-// in LDS as [pixel][channel]; the MFMA operand fetch is one ds_read_b32 per lane
-// (lanes 0-31 = consecutive channels => conflict-free).
+// Tile: BC (cout) x 128 or 256 (k) accumulators, 32 pixels per step.  dy and A tiles are staged
+// in LDS as [pixel][channel]; v_mfma_f32_16x16x4_f32 operands are fetched with ds_read_b128 / b64
+// (one wide read feeds 4 / 2 MFMA tiles, see Frag).
 #include "common.h"
 #include <cstdlib>
 
@@ -30,6 +30,7 @@ struct WgradParams {
   int dy_sw;
   long long dy_off;
   int frame;  // GEMM rows enumerate only the 2-pixel border frame of the Ho x Wo output (see decode_pixel)
+  unsigned x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST loader (0 when >= 2 GiB)
 };
 
 // row index -> (sample, output row, output column); same enumeration as conv_igemm.hip
@@ -57,46 +58,57 @@ __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, in
   }
 }
 
-// advance a (b, oh, ow) pixel of the linear Ho x Wo enumeration by WPX pixels
-template <int WPX>
-__device__ inline void advance_pixel(int& b, int& oh, int& ow, int Ho, int Wo) {
-  if (Wo >= WPX) {  // wave-uniform: at most one row wrap per step, done with selects
-    int w = ow + WPX;
-    const bool wrap = w >= Wo;
-    w -= wrap ? Wo : 0;
-    const int h = oh + (wrap ? 1 : 0);
-    const bool wrap2 = h >= Ho;
-    ow = w;
-    oh = wrap2 ? 0 : h;
-    b += wrap2 ? 1 : 0;
-  } else {
-    ow += WPX;
-    while (ow >= Wo) {
-      ow -= Wo;
-      if (++oh == Ho) { oh = 0; ++b; }
-    }
-  }
-}
-
-
 constexpr int WP = 32;   // pixels per step
 
 constexpr int WTHR = 512;
 
-template <int BC, bool ALIGNED>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;   // buffer-load offset past any (< 2 GiB) tensor: the load returns zeros
+
+// Operand fragments of v_mfma_f32_16x16x4_f32 straight out of a [pixel][channel] LDS tile.  Lane l
+// supplies (row j = l&15, contraction index g = l>>4).  One wide read of NTILE consecutive channels
+// starting at NTILE*j feeds NTILE MFMA tiles at once: tile t holds channels {NTILE*j + t}, a permutation
+// of the wave's channel range that the epilogue undoes.  b128 rows (NTILE=4) are conflict-free as they
+// are; b64 rows (NTILE=2) XOR the column with 32*(pixel&1) so that the two pixel rows of a 32-lane group
+// fall on different banks.
+template <int NTILE>
+struct Frag;
+template <>
+struct Frag<4> {
+  f32x4 v;
+  __device__ inline void load(const float* row, int col, int /*swz*/) { v = *reinterpret_cast<const f32x4*>(row + col); }
+  __device__ inline float at(int t) const { return v[t]; }
+};
+template <>
+struct Frag<2> {
+  f32x2 v;
+  __device__ inline void load(const float* row, int col, int swz) { v = *reinterpret_cast<const f32x2*>(row + (col ^ swz)); }
+  __device__ inline float at(int t) const { return v[t]; }
+};
+
+// FAST = Cin % 4 == 0 && Cout % 4 == 0 && linear pixel enumeration && tensors < 2 GiB: the tile loads are
+// straight-line buffer loads with 32-bit offsets (invalid rows get an out-of-range offset and read as
+// zero), the pixel walk is a carry chain without divisions -- ~1/4 of the generic loader's VALU work,
+// which at 16 MFMAs per wave and step was the limiter.
+template <int BC, bool ALIGNED, bool FAST>
 __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
-  // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64), so every
-  // wave owns two 32x32 accumulators either way (2 cout tiles x 1 k tile, or 1 x 2).
+  // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64): every wave
+  // owns eight 16x16 accumulators either way (4 cout tiles x 2 k tiles, or 2 x 4).
   constexpr int WKT = BC == 128 ? 128 : 256;
-  constexpr int NTK = WKT / 128;        // 32-col MFMA tiles per wave along k
+  constexpr int WC = BC / 2;            // cout rows per wave: 64 or 32
+  constexpr int WK = WKT / 4;           // k columns per wave: 32 or 64
+  constexpr int MT = WC / 16;           // 16-row MFMA tiles per wave along cout: 4 or 2
+  constexpr int NT = WK / 16;           // 16-col MFMA tiles per wave along k: 2 or 4
   constexpr int XQ = WKT / 4;           // float4 per gathered row
   constexpr int XRPT = WTHR / XQ;       // gather rows covered per pass of the block: 16 or 8
   constexpr int XROWS = WP / XRPT;      // gather rows per loader thread: 2 or 4
-  constexpr int WC = BC / 2;            // cout rows per wave
-  constexpr int MT = WC / 32;           // 32-row MFMA tiles per wave along cout: 2 (BC=128) or 1
   constexpr int DQ = BC / 4;            // float4 per dy row
   constexpr int DRPT = WTHR / DQ;       // dy rows covered per pass of the block: 16 or 32
   constexpr int DROWS = WP / DRPT;      // dy rows per loader thread: 2 or 1
+  constexpr int SWZ_D = MT == 2 ? 32 : 0;
+  constexpr int SWZ_X = NT == 2 ? 32 : 0;
+  static_assert(XRPT % 2 == 0 && DRPT % 2 == 0, "row parity of a loader thread must not change between passes");
   __shared__ __attribute__((aligned(16))) float Ds[2 * WP * BC];   // double-buffered: one barrier per step
   __shared__ __attribute__((aligned(16))) float Xs[2 * WP * WKT];
 
@@ -138,33 +150,94 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   // dy-tile loader: thread -> (row = tid / DQ + DRPT * i, q = tid % DQ)
   const int dq = tid % DQ;
   const int dr0 = tid / DQ;
+  // LDS destinations of this thread's float4s (row parity is the same for all of its rows)
+  const int xs_col = (xq * 4) ^ ((xr0 & 1) ? SWZ_X : 0);
+  const int ds_col = (dq * 4) ^ ((dr0 & 1) ? SWZ_D : 0);
 
   f32x4 rx[XROWS], rd[DROWS];
 
-  // pixel coordinates of this thread's gather rows and dy rows, advanced incrementally by 32 pixels per
-  // step (one division per row up front instead of per step); frame mode decodes each step
-  int px_oh[XROWS], px_ow[XROWS], px_b[XROWS];
+  // FAST: pixel coordinates of this thread's gather rows and dy rows, walked 32 pixels per step (one
+  // division per row up front); the generic loader decodes every step instead (fewer live registers)
+  int px_oh[FAST ? XROWS : 1], px_ow[FAST ? XROWS : 1], px_b[FAST ? XROWS : 1];
+  int dp_oh[FAST ? DROWS : 1], dp_ow[FAST ? DROWS : 1], dp_b[FAST ? DROWS : 1];
+  if constexpr (FAST) {
 #pragma unroll
-  for (int i = 0; i < XROWS; ++i) {
-    int m = m_begin + xr0 + XRPT * i;
-    decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, p.frame, px_b[i], px_oh[i], px_ow[i]);
-  }
-  int dp_oh[DROWS], dp_ow[DROWS], dp_b[DROWS];
+    for (int i = 0; i < XROWS; ++i) {
+      int m = m_begin + xr0 + XRPT * i;
+      decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, 0, px_b[i], px_oh[i], px_ow[i]);
+    }
 #pragma unroll
-  for (int i = 0; i < DROWS; ++i) {
-    int m = m_begin + dr0 + DRPT * i;
-    decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, p.frame, dp_b[i], dp_oh[i], dp_ow[i]);
+    for (int i = 0; i < DROWS; ++i) {
+      int m = m_begin + dr0 + DRPT * i;
+      decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, 0, dp_b[i], dp_oh[i], dp_ow[i]);
+    }
   }
+  // FAST: a step of 32 pixels = step_b samples + step_h rows + step_w columns (uniform), applied with carries
+  const int hw = p.Ho * p.Wo;
+  const int step_b = WP / hw;
+  const int step_h = (WP - step_b * hw) / p.Wo;
+  const int step_w = WP - step_b * hw - step_h * p.Wo;
+  // FAST: float offset of the dy row, walked with the same carries
+  int dp_off[DROWS];
+  const int d_step = step_b * (int)p.dy_sb + step_h * (int)p.dy_sh + step_w * p.dy_sw;
+  const int d_carry_w = (int)p.dy_sh - p.Wo * p.dy_sw;          // column wrapped: next row
+  const int d_carry_h = (int)p.dy_sb - p.Ho * (int)p.dy_sh;     // row wrapped: next sample
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < DROWS; ++i)
+      dp_off[i] = dp_b[i] * (int)p.dy_sb + dp_oh[i] * (int)p.dy_sh + dp_ow[i] * p.dy_sw + (int)p.dy_off + co0 + dq * 4;
+  }
+  const bool d_col_ok = co0 + dq * 4 < p.Cout;
 
   auto load_tiles = [&](int mbase) {
+    if constexpr (FAST) {
+      const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) {
+        const int m = mbase + xr0 + XRPT * i;
+        const int ih = src_coord(__mul24(px_oh[i], p.stride) - p.pad + ekh[0], p.Hu, p.ups, p.reflect);
+        const int iw = src_coord(__mul24(px_ow[i], p.stride) - p.pad + ekw[0], p.Wu, p.ups, p.reflect);
+        const bool ok = m < m_end && eok[0] && ih >= 0 && iw >= 0;
+        // 24-bit multiplies: the host checked B*H*W < 2^23 and x_bytes < 2^31
+        const int pix = __mul24(__mul24(px_b[i], p.H) + ih, p.W) + iw;
+        const unsigned off = (unsigned)(__mul24(pix, p.Cin) + eci[0]) * 4u;
+        rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? off : OOB, 0, 0));
+        // walk 32 pixels on
+        int ow = px_ow[i] + step_w;
+        const bool cw = ow >= p.Wo;
+        ow -= cw ? p.Wo : 0;
+        int oh = px_oh[i] + step_h + (cw ? 1 : 0);
+        const bool ch = oh >= p.Ho;
+        oh -= ch ? p.Ho : 0;
+        px_ow[i] = ow;
+        px_oh[i] = oh;
+        px_b[i] += step_b + (ch ? 1 : 0);
+      }
+#pragma unroll
+      for (int i = 0; i < DROWS; ++i) {
+        const int m = mbase + dr0 + DRPT * i;
+        const bool ok = m < m_end && d_col_ok;
+        rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dres, ok ? (unsigned)dp_off[i] * 4u : OOB, 0, 0));
+        int ow = dp_ow[i] + step_w;
+        const bool cw = ow >= p.Wo;
+        ow -= cw ? p.Wo : 0;
+        int oh = dp_oh[i] + step_h + (cw ? 1 : 0);
+        const bool ch = oh >= p.Ho;
+        oh -= ch ? p.Ho : 0;
+        dp_ow[i] = ow;
+        dp_oh[i] = oh;
+        dp_off[i] += d_step + (cw ? d_carry_w : 0) + (ch ? d_carry_h : 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < XROWS; ++i) {
       const int m = mbase + xr0 + XRPT * i;
       const bool mok = m < m_end;
-      if (p.frame) decode_pixel(mok ? m : 0, p.Ho, p.Wo, 1, px_b[i], px_oh[i], px_ow[i]);
-      const int oh = px_oh[i], ow = px_ow[i];
-      const long long base = (long long)px_b[i] * p.H * p.W;
-      if (!p.frame) advance_pixel<WP>(px_b[i], px_oh[i], px_ow[i], p.Ho, p.Wo);
+      int b, oh, ow;
+      decode_pixel(mok ? m : 0, p.Ho, p.Wo, p.frame, b, oh, ow);
+      const long long base = (long long)b * p.H * p.W;
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if constexpr (ALIGNED) {
@@ -188,10 +261,10 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
     for (int i = 0; i < DROWS; ++i) {
       const int m = mbase + dr0 + DRPT * i;
       const bool mok = m < m_end;
-      if (p.frame) decode_pixel(mok ? m : 0, p.Ho, p.Wo, 1, dp_b[i], dp_oh[i], dp_ow[i]);
-      const float* ptr = p.dy + (long long)dp_b[i] * p.dy_sb + (long long)dp_oh[i] * p.dy_sh +
-                         (long long)dp_ow[i] * p.dy_sw + p.dy_off + co0 + dq * 4;
-      if (!p.frame) advance_pixel<WP>(dp_b[i], dp_oh[i], dp_ow[i], p.Ho, p.Wo);
+      int b, oh, ow;
+      decode_pixel(mok ? m : 0, p.Ho, p.Wo, p.frame, b, oh, ow);
+      const float* ptr = p.dy + (long long)b * p.dy_sb + (long long)oh * p.dy_sh + (long long)ow * p.dy_sw +
+                         p.dy_off + co0 + dq * 4;
       const int co = co0 + dq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (mok) {
@@ -210,38 +283,50 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
     float* Xd = Xs + buf * (WP * WKT);
     float* Dd = Ds + buf * (WP * BC);
 #pragma unroll
-    for (int i = 0; i < XROWS; ++i) *reinterpret_cast<f32x4*>(&Xd[(xr0 + XRPT * i) * WKT + xq * 4]) = rx[i];
+    for (int i = 0; i < XROWS; ++i) *reinterpret_cast<f32x4*>(&Xd[(xr0 + XRPT * i) * WKT + xs_col]) = rx[i];
 #pragma unroll
-    for (int i = 0; i < DROWS; ++i) *reinterpret_cast<f32x4*>(&Dd[(dr0 + DRPT * i) * BC + dq * 4]) = rd[i];
+    for (int i = 0; i < DROWS; ++i) *reinterpret_cast<f32x4*>(&Dd[(dr0 + DRPT * i) * BC + ds_col]) = rd[i];
   };
 
-  f32x16 acc[MT][NTK];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int t = 0; t < NTK; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[a][t][r] = 0.f;
   float bsum = 0.f;  // bias column sum: thread tid < BC owns channel co0 + tid
   const bool do_bias = p.bias_slab != nullptr && blockIdx.x == 0;
 
-  const int fr = lane & 31;
-  const int fk = lane >> 5;
-  auto compute_half = [&](int buf, int k0) {
+  const int fj = lane & 15;   // operand row / column inside a 16x16 tile
+  const int fg = lane >> 4;   // pixel inside a group of 4
+  const int a_col = wm * WC + MT * fj;
+  const int b_col = wn * WK + NT * fj;
+  const int a_swz = (fg & 1) ? SWZ_D : 0;
+  const int b_swz = (fg & 1) ? SWZ_X : 0;
+  // 16 of the 32 pixels of a step: wide LDS reads for GB pixel groups at a time, then GB * MT * NT MFMAs
+  // (the generic loader keeps more per-row state in registers and takes smaller batches)
+  constexpr int GB = (FAST || BC == 128) ? 4 : 2;
+  auto compute_half = [&](int buf, int p0) {
     const float* Dc = Ds + buf * (WP * BC);
     const float* Xc = Xs + buf * (WP * WKT);
 #pragma unroll
-    for (int kk = k0; kk < k0 + WP / 2; kk += 2) {
-      float a[MT], b[NTK];
+    for (int s0 = 0; s0 < 4; s0 += GB) {
+      Frag<MT> a[GB];
+      Frag<NT> b[GB];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[t] = Dc[(kk + fk) * BC + wm * WC + t * 32 + fr];
+      for (int s = 0; s < GB; ++s) {
+        a[s].load(Dc + (p0 + 4 * (s0 + s) + fg) * BC, a_col, a_swz);
+        b[s].load(Xc + (p0 + 4 * (s0 + s) + fg) * WKT, b_col, b_swz);
+      }
 #pragma unroll
-      for (int t = 0; t < NTK; ++t) b[t] = Xc[(kk + fk) * WKT + wn * (32 * NTK) + t * 32 + fr];
+      for (int s = 0; s < GB; ++s)
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < NTK; ++u)
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].at(t), b[s].at(u), acc[t][u], 0, 0, 0);
+      if constexpr (GB != 4) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -264,23 +349,35 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
     if (do_bias && tid < BC) {
       const float* Dc = Ds + cur * (WP * BC);
 #pragma unroll 8
-      for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + tid];
+      for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
     }
     __syncthreads();
     cur ^= 1;
   }
 
   // ---- write the partial tile: slab[split][co][k] ----
+  // accumulator (t, u), register r of lane (fj, fg): cout row MT*(4*fg + r) + t, k column NT*fj + u
   float* out = p.slab + (long long)split * p.Cout * p.Ktot;
+  const int k_base = kc0 + wn * WK + NT * fj;
 #pragma unroll
-  for (int s = 0; s < MT; ++s) {
+  for (int t = 0; t < MT; ++t) {
 #pragma unroll
-    for (int u = 0; u < NTK; ++u) {
-      const int k = kc0 + wn * (32 * NTK) + u * 32 + (lane & 31);
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wm * WC + MT * (4 * fg + r) + t;
+      if (co >= p.Cout) continue;
+      float* dst = out + (long long)co * p.Ktot + k_base;
+      if (ALIGNED && k_base + NT <= p.Ktot) {   // Ktot % 4 == 0 when aligned: NT consecutive columns, vector store
+        if constexpr (NT == 2) {
+          f32x2 v = {acc[t][0][r], acc[t][1][r]};
+          *reinterpret_cast<f32x2*>(dst) = v;
+        } else {
+          f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int co = co0 + wm * WC + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[s][u][r];
+        for (int u = 0; u < NT; ++u)
+          if (k_base + u < p.Ktot) dst[u] = acc[t][u][r];
       }
     }
   }
@@ -314,11 +411,11 @@ int wgrad_blocks_per_cu(int bc, bool aligned) {
     int n = 0;
     hipError_t e;
     if (bc == 128) {
-      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, true>, WTHR, 0);
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, false>, WTHR, 0);
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, true, true>, WTHR, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<128, false, false>, WTHR, 0);
     } else {
-      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, true>, WTHR, 0);
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, false>, WTHR, 0);
+      if (aligned) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, true, true>, WTHR, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wgrad_kernel<64, false, false>, WTHR, 0);
     }
     if (e != hipSuccess) (void)hipGetLastError();  // e.g. no device in the build container
     c = (e == hipSuccess && n > 0) ? std::min(n, 8) : 2;
@@ -387,12 +484,20 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   p.bias_slab = db ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.slab_bytes) : nullptr;
   p.pix_per_split = pl.pix_per_split;
   dim3 grid((unsigned)pl.k_tiles, (unsigned)pl.c_tiles, (unsigned)pl.nsplit);
+  // FAST loader: 32-bit byte offsets and 24-bit multiplies (see the kernel)
+  const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, db_ = (long long)p.B * p.dy_sb * 4;
+  const bool fast = aligned && (p.Cout % 4 == 0) && !p.frame && xb < (1ll << 31) && db_ < (1ll << 31) &&
+                    (long long)p.B * p.H * p.W < (1ll << 23) && !getenv("MUNIT_DEBUG_NO_FAST_WGRAD");
+  p.x_bytes = fast ? (unsigned)xb : 0u;
+  p.dy_bytes = fast ? (unsigned)db_ : 0u;
   if (pl.bc == 64) {
-    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), grid, dim3(WTHR), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), grid, dim3(WTHR), 0, st, p);
+    if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true>), grid, dim3(WTHR), 0, st, p);
+    else if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, false>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, false, false>), grid, dim3(WTHR), 0, st, p);
   } else {
-    if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<128, true>), grid, dim3(WTHR), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), grid, dim3(WTHR), 0, st, p);
+    if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true>), grid, dim3(WTHR), 0, st, p);
+    else if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<128, true, false>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, false, false>), grid, dim3(WTHR), 0, st, p);
   }
   MUNIT_CHECK_LAUNCH("conv_wgrad");
   const long long n = (long long)p.Cout * p.Ktot;

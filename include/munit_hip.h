@@ -49,7 +49,7 @@ const char* munit_last_error(void);
  *   x: [B][H][W][Cin]   w: [Cout][KH][KW][Cin]   bias: [Cout] or NULL
  *   y: [B][Ho][Wo][Cout],  Ho = ((H << upsample) + 2*pad - KH) / stride + 1
  * act is applied after the bias (MUNIT_ACT_*; slope = LeakyReLU negative slope).
- * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged NHWC tiles.
+ * Implicit-GEMM on v_mfma_f32_16x16x4_f32 (exact fp32), LDS-staged NHWC tiles.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
   int B, H, W, Cin;
@@ -169,6 +169,38 @@ int munit_extraadam_step(float* p, const float* g, float* m, float* v, float* p_
 
 /* y[i] = alpha * x[i] (+ y[i] if accumulate); used for the 1/world gradient averaging. */
 int munit_scale(const float* x, float* y, size_t n, float alpha, int accumulate, munit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Input pipeline.  Replaces the per-image torchvision/PIL chain of the
+ * reference's loaders -- RandomHorizontalFlip -> Resize(new_size) -> RandomCrop -> ToTensor ->
+ * Normalize(0.5, 0.5) (scripts/utils.py:229-249, 717-738; MyDataset.transform, utils.py:296-345) --
+ * with one batched device pass over decoded uint8 images of different sizes.  The resize is Pillow's
+ * BILINEAR resampler (anti-aliased, 22-bit fixed point, uint8 between the passes) restated bit-exactly.
+ *   pool : device bytes holding the decoded images back to back (RGB, HWC interleaved; masks 1 byte/pixel)
+ *   descs: device array of B descriptors (the random draws are made by the host loader)
+ *   out  : images [B][out_h][out_w][3] fp32 in [-1, 1]; masks [B][out_h][out_w] fp32
+ * ksize_max >= munit_image_ksize(src, rs) of every image axis in the batch (filter taps per output).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  long long src_off;  /* byte offset of the image in pool */
+  int src_h, src_w;   /* decoded size */
+  int rs_h, rs_w;     /* size after Resize (= src size when no resize); unused for masks */
+  int crop_i, crop_j; /* top-left corner of the crop window in the resized image */
+  int flip;           /* 1: flipped left-right before the resize */
+  int reserved;
+} munit_image_desc;
+
+int munit_image_ksize(int src_size, int rs_size);
+size_t munit_image_preprocess_workspace_bytes(int B, int out_h, int out_w, int ksize_max);
+int munit_image_preprocess(const unsigned char* pool, const munit_image_desc* descs, int B, int out_h,
+                           int out_w, int ksize_max, float* out, void* ws, size_t ws_bytes,
+                           munit_stream_t stream);
+/* Mask chain of MyDataset.transform (utils.py:318-330): flip, NEAREST resize of the whole mask to
+ * (out_w, out_h), crop of that image at (crop_j, crop_i) with zero fill past its edge (what the reference
+ * computes), ToTensor, and x255 for samples whose maximum is 1. */
+size_t munit_mask_preprocess_workspace_bytes(int B, int out_h, int out_w);
+int munit_mask_preprocess(const unsigned char* pool, const munit_image_desc* descs, int B, int out_h,
+                          int out_w, float* out, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 #ifdef __cplusplus
 }

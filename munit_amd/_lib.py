@@ -23,6 +23,12 @@ class ConvDesc(Structure):
                 ("upsample", c_int), ("act", c_int), ("slope", c_float)]
 
 
+class ImageDesc(Structure):
+    """munit_image_desc."""
+    _fields_ = [("src_off", ctypes.c_longlong), ("src_h", c_int), ("src_w", c_int), ("rs_h", c_int), ("rs_w", c_int),
+                ("crop_i", c_int), ("crop_j", c_int), ("flip", c_int), ("reserved", c_int)]
+
+
 _P = c_void_p  # device pointers travel as integers
 _DESC = POINTER(ConvDesc)
 
@@ -62,6 +68,11 @@ SIGNATURES = {
     "munit_extraadam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double,
                                      c_double, c_int, c_int, _P]),
     "munit_scale": (c_int, [_P, _P, c_size_t, c_float, c_int, _P]),
+    "munit_image_ksize": (c_int, [c_int, c_int]),
+    "munit_image_preprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "munit_image_preprocess": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "munit_mask_preprocess_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "munit_mask_preprocess": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
 }
 
 _lib = None

@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmunit_hip.so")
+# MUNIT_HIP_LIB: developer override used by tools/ab_bench.sh to A/B two builds of the library in one GPU session
+LIB_PATH = os.environ.get("MUNIT_HIP_LIB") or os.path.join(_HERE, "libmunit_hip.so")
 
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 PAD = {"zero": 0, "reflect": 1}

@@ -79,7 +79,12 @@ __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, in
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int NTHR = 512;
+#ifndef IGEMM_WAVES
+#define IGEMM_WAVES 8
+#endif
+constexpr int NWAVES = IGEMM_WAVES;   // 8: wave tile 64x32 (BN=128), four waves per SIMD; 4: wave tile 64x64, two per SIMD
+constexpr int NTHR = 64 * NWAVES;
+constexpr int RSTEP = NTHR / 8;       // loader rows covered per pass of the block (8 float4 per 32-wide K row)
 constexpr int LDS_LD = BK + 4;
 
 // Padded/up-sampled coordinates whose gradient folds onto source coordinate i (adjoint of
@@ -117,20 +122,20 @@ __device__ inline int cand_at(uint2 v, int a) {
 // before the MFMA -- exact, because the GEMM is linear in A -- which removes the padded-domain
 // buffer and, for the up-sampling convs, 4x of the MFMA work).
 template <int BN, bool ALIGNED, int ROLE>
-__global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
   // waves gather (measured MfmaUtil 73 % with 4 waves / 210 registers -> see profiles/).
-  constexpr int WAVES_N = BN / 32;            // 4 (BN=128) or 2 (BN=64): every wave owns 32 output channels
-  constexpr int WAVES_M = 8 / WAVES_N;        // 2 or 4
+  constexpr int WN = NWAVES == 8 ? 32 : 64;   // output channels per wave
+  constexpr int WAVES_N = BN / WN;
+  constexpr int WAVES_M = NWAVES / WAVES_N;
   constexpr int WM = BM / WAVES_M;            // rows per wave: 64 or 32
   // v_mfma_f32_16x16x4_f32 tiles: measured on MI355X the 16x16x4 form sustains ~20 % more FLOP/s than
   // 32x32x2 at the clocks the power manager grants under matrix load (tools/ubench/mfma_peak.hip); same
   // LDS operand traffic per FLOP, same exact-f32 fma chain.
   constexpr int MT = WM / 16;                 // 16-row MFMA tiles per wave: 4 or 2
-  constexpr int NT = 2;
-  constexpr int WN = 32;
-  constexpr int AROWS = BM / 64;              // gather rows per loader thread (512 threads x float4 = 64 rows)
-  constexpr int BROWS = BN / 64;              // weight rows per loader thread
+  constexpr int NT = WN / 16;
+  constexpr int AROWS = BM / RSTEP;           // gather rows per loader thread (512 threads x float4 = 64 rows)
+  constexpr int BROWS = BN / RSTEP;           // weight rows per loader thread
   // double-buffered A/B tiles: one barrier per K-tile (72 KiB at BN=128: two blocks per CU)
   __shared__ __attribute__((aligned(16))) float As[2 * BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDS_LD];
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
   int a_nc[AROWS];                 // ROLE 2 only: candidate counts (rows | cols << 4)
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    int m = m0 + r0 + 64 * i;
+    int m = m0 + r0 + RSTEP * i;
     a_ok[i] = m < p.M;
     int mm = a_ok[i] ? m : 0;
     int b, oh, ow;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        const int n = n0 + r0 + 64 * i;
+        const int n = n0 + r0 + RSTEP * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         // k index is linear in the tile number: tap*Cin + c0 == kt*BK
         if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(wg + (long long)n * p.w_row + kt * BK + c4 * 4);
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
-        int n = n0 + r0 + 64 * i;
+        int n = n0 + r0 + RSTEP * i;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -344,11 +349,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       if constexpr (ROLE == 2) ra[i] += rx[i];
-      *reinterpret_cast<f32x4*>(&Ad[(r0 + 64 * i) * LDS_LD + c4 * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Ad[(r0 + RSTEP * i) * LDS_LD + c4 * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<f32x4*>(&Bd[(r0 + 64 * i) * LDS_LD + c4 * 4]) = rb[i];
+      *reinterpret_cast<f32x4*>(&Bd[(r0 + RSTEP * i) * LDS_LD + c4 * 4]) = rb[i];
   };
 
   f32x4 acc[MT][NT];

@@ -35,6 +35,11 @@ typedef void* munit_stream_t; /* hipStream_t */
 enum { MUNIT_OK = 0, MUNIT_ERR_ARG = -1, MUNIT_ERR_WORKSPACE = -2, MUNIT_ERR_LAUNCH = -3 };
 enum { MUNIT_ACT_NONE = 0, MUNIT_ACT_RELU = 1, MUNIT_ACT_LRELU = 2, MUNIT_ACT_TANH = 3 };
 enum { MUNIT_PAD_ZERO = 0, MUNIT_PAD_REFLECT = 1 };
+/* MUNIT_COMPUTE_F32: exact fp32 MFMA (the reference's arithmetic).  MUNIT_COMPUTE_BF16: operands rounded to
+ * bf16 (nearest-even) as they are staged into LDS, v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the
+ * bf16 mode of BASELINE.json config #3, a build extension with no reference counterpart.  Layers whose
+ * channel count is not a multiple of 32 (the 3-channel image layers) stay fp32 in both modes. */
+enum { MUNIT_COMPUTE_F32 = 0, MUNIT_COMPUTE_BF16 = 1 };
 
 int munit_version(void);
 const char* munit_last_error(void);
@@ -58,6 +63,7 @@ typedef struct {
   int upsample;              /* 0 or 1: nearest x2 of x before padding */
   int act;                   /* MUNIT_ACT_* fused after bias (fwd only) */
   float slope;
+  int compute;               /* MUNIT_COMPUTE_*: arithmetic of the contraction (tensors are fp32 either way) */
 } munit_conv_desc;
 
 int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo);

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MUNIT_HIP_LIB") or os.path.join(_HERE, "libmunit_hip.
 
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 PAD = {"zero": 0, "reflect": 1}
+COMPUTE = {"f32": 0, "bf16": 1}
 
 
 class ConvDesc(Structure):
@@ -21,7 +22,7 @@ class ConvDesc(Structure):
     _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("pad_mode", c_int),
-                ("upsample", c_int), ("act", c_int), ("slope", c_float)]
+                ("upsample", c_int), ("act", c_int), ("slope", c_float), ("compute", c_int)]
 
 
 class ImageDesc(Structure):

@@ -50,6 +50,7 @@ struct IgemmParams {
   // slab[(phase*ksplit + z)][M][Cout] and splitk_epilogue_kernel sums them in order (+bias, act)
   int ksplit, kt_per_split;
   float* slab;
+  int bf16;  // operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (aligned variants only)
 };
 
 // row index -> (sample, output row, output column)
@@ -121,8 +122,15 @@ __device__ inline int cand_at(uint2 v, int a) {
 // the gathered dy values of every padded/up-sampled position that maps to the pixel are summed
 // before the MFMA -- exact, because the GEMM is linear in A -- which removes the padded-domain
 // buffer and, for the up-sampling convs, 4x of the MFMA work).
-template <int BN, bool ALIGNED, int ROLE>
+// BF16 = operands rounded to bf16 (RNE) when they are staged into LDS and multiplied with
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulate; tensors stay fp32 in HBM): the "bf16 compute" mode of
+// BASELINE.json config #3.  Aligned variants only.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BN, bool ALIGNED, int ROLE, bool BF16 = false>
 __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
+  static_assert(!BF16 || ALIGNED, "bf16 operands need Cin % 32 == 0");
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
   // waves gather (measured MfmaUtil 73 % with 4 waves / 210 registers -> see profiles/).
   constexpr int WN = NWAVES == 8 ? 32 : 64;   // output channels per wave
@@ -346,7 +354,34 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
     }
   };
 
+  // bf16 tiles: [row][32] bf16 = 64-byte rows without padding; the 16-byte chunk c of a row lives at
+  // position c ^ F[(row>>2)&3], F = {0,2,3,1}, which makes the fragment ds_read_b128 conflict-free
+  // (every 16-lane service group then touches 16 distinct (row&3, position) pairs = all 64 banks).
+  __bf16* const Ah = reinterpret_cast<__bf16*>(smem);
+  __bf16* const Bh = Ah + 2 * BM * 32;
+  const int st_swz = (0x78 >> (2 * ((r0 >> 2) & 3))) & 3;     // RSTEP % 16 == 0: the same for all rows of a thread
+  const int st_col = (((c4 >> 1) ^ st_swz) * 8) + (c4 & 1) * 4;  // bf16 index inside the row
   auto store_tile = [&](int buf) {
+    if constexpr (BF16) {
+      __bf16* Ad = Ah + buf * (BM * 32);
+      __bf16* Bd = Bh + buf * (BN * 32);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        if constexpr (ROLE == 2) ra[i] += rx[i];
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e];
+        *reinterpret_cast<bf16x4*>(&Ad[(r0 + RSTEP * i) * 32 + st_col]) = h;
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[i][e];
+        *reinterpret_cast<bf16x4*>(&Bd[(r0 + RSTEP * i) * 32 + st_col]) = h;
+      }
+      return;
+    }
     float* Ad = As + buf * (BM * LDS_LD);
     float* Bd = Bs + buf * (BN * LDS_LD);
 #pragma unroll
@@ -373,7 +408,25 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   const int frag_row = lane & 15;
   const int frag_k = (lane >> 4) * 4;
   // one of the two 16-wide k groups of a K-tile: (MT + NT) ds_read_b128, 4 * MT * NT MFMAs
+  const int fr_col = (((lane >> 4) ^ ((0x78 >> (2 * ((frag_row >> 2) & 3))) & 3)) * 8);   // bf16 fragment chunk
   auto compute_half = [&](int buf, int kg) {
+    if constexpr (BF16) {
+      // one v_mfma_f32_16x16x32_bf16 per tile pair covers the whole 32-deep K-tile: half kg takes half of the row tiles
+      const __bf16* Ac = Ah + buf * (BM * 32);
+      const __bf16* Bc = Bh + buf * (BN * 32);
+      bf16x8 hb[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        hb[nt] = *reinterpret_cast<const bf16x8*>(&Bc[(wn * WN + nt * 16 + frag_row) * 32 + fr_col]);
+#pragma unroll
+      for (int mt = kg * (MT / 2); mt < (kg + 1) * (MT / 2); ++mt) {
+        const bf16x8 ha = *reinterpret_cast<const bf16x8*>(&Ac[(wm * WM + mt * 16 + frag_row) * 32 + fr_col]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[nt], acc[mt][nt], 0, 0, 0);
+      }
+      return;
+    }
     const float* Ac = As + buf * (BM * LDS_LD);
     const float* Bc = Bs + buf * (BN * LDS_LD);
     f32x4 a[MT], b[NT];
@@ -689,13 +742,20 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       munit_set_error("conv_igemm: folded backward-data needs Cout %% 32 == 0");
       return MUNIT_ERR_ARG;
     }
-    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2>), grid, block, 0, st, q);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
+    if (bn == 64) {
+      if (p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, true>), grid, block, 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2>), grid, block, 0, st, q);
+    } else {
+      if (p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, true>), grid, block, 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
+    }
   } else if (bn == 64) {
-    if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE>), grid, block, 0, st, q);
+    if (aligned && p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, true>), grid, block, 0, st, q);
+    else if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false, ROLE>), grid, block, 0, st, q);
   } else {
-    if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE>), grid, block, 0, st, q);
+    if (aligned && p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, true>), grid, block, 0, st, q);
+    else if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, false, ROLE>), grid, block, 0, st, q);
   }
   MUNIT_CHECK_LAUNCH("conv_igemm");
@@ -713,6 +773,7 @@ int check_desc(const munit_conv_desc* d) {
   MUNIT_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims");
   MUNIT_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
   MUNIT_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv: upsample must be 0 or 1");
+  MUNIT_CHECK_ARG(d->compute == MUNIT_COMPUTE_F32 || d->compute == MUNIT_COMPUTE_BF16, "conv: bad compute mode %d", d->compute);
   MUNIT_CHECK_ARG(d->pad_mode == MUNIT_PAD_ZERO || d->pad_mode == MUNIT_PAD_REFLECT, "conv: bad pad mode");
   const int Hu = d->H << d->upsample, Wu = d->W << d->upsample;
   if (d->pad_mode == MUNIT_PAD_REFLECT)
@@ -775,6 +836,7 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
   p.y_sb = (long long)Ho * Wo * d->Cout;
   p.M = d->B * Ho * Wo;
   p.act = d->act; p.slope = d->slope;
+  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
   p.ps = 1;
   if (subpixel_ok(d)) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
@@ -934,6 +996,8 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     p.y_sb = (long long)d->H * d->W * d->Cin;
     p.M = d->B * d->H * d->W;
     p.act = MUNIT_ACT_NONE; p.slope = 0.f;
+  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
+    p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
@@ -962,6 +1026,7 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
   p.y_sb = (long long)pl.Hq * pl.Wq * d->Cin;
   p.M = d->B * p.Ho * p.Wo;
   p.act = MUNIT_ACT_NONE; p.slope = 0.f;
+  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
   p.ps = pl.ps;
   p.w_phase = (long long)d->Cin * p.Ktot;
   p.y_phase_row = (long long)pl.Wq * d->Cin;

@@ -16,12 +16,28 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._lib import ACT, PAD, ConvDesc
+from ._lib import ACT, COMPUTE, PAD, ConvDesc
 
 _ws_cache = {}
 # bench.py sets this to a list to time every forward-conv launch with HIP events on the launch stream:
 # entries are (kernel variant tag, algorithmic FLOPs, start event, end event).
 PROFILE = None
+
+
+# Arithmetic of the conv / linear contractions: "f32" (exact fp32 MFMA, the reference's arithmetic) or "bf16"
+# (operands rounded to bf16 in LDS, fp32 accumulate; BASELINE.json config #3).  Process-wide: set by the trainer.
+_COMPUTE = 0
+
+
+def set_compute(mode):
+    global _COMPUTE
+    if mode not in COMPUTE:
+        raise ValueError("munit_amd: compute mode must be one of %s, got %r" % (sorted(COMPUTE), mode))
+    _COMPUTE = COMPUTE[mode]
+
+
+def get_compute():
+    return [k for k, v in COMPUTE.items() if v == _COMPUTE][0]
 
 
 def _require(t, name="tensor"):
@@ -79,7 +95,7 @@ def _desc(x, weight, stride, pad, pad_type, upsample, act="none", slope=0.2):
     if cin_w != cin:
         raise RuntimeError("munit_amd.conv2d: weight expects %d input channels, input has %d" % (cin_w, cin))
     return ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), ACT[act],
-                    float(slope))
+                    float(slope), _COMPUTE)
 
 
 def _out_hw(d):
@@ -121,7 +137,7 @@ def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=N
     dy, weight = nhwc(dy), nhwc(weight)
     b, cin, h, w = x_shape
     cout, _, kh, kw = weight.shape
-    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0)
+    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0, _COMPUTE)
     nbytes = lib.munit_conv2d_dgrad_workspace_bytes(byref(d))
     ws = workspace(nbytes, dy.device)
     dx = empty_nhwc(b, cin, h, w, dy)
@@ -139,7 +155,7 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
     x, dy = nhwc(x), nhwc(dy)
     b, cin, h, w = x.shape
     cout, _, kh, kw = weight_shape
-    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0)
+    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0, _COMPUTE)
     nbytes = lib.munit_conv2d_wgrad_workspace_bytes(byref(d))
     ws = workspace(nbytes, x.device)
     if dw is None:

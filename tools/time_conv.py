@@ -2,6 +2,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from munit_amd import ops
+if len(sys.argv) > 1: ops.set_compute(sys.argv[1])   # "f32" (default) or "bf16"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 x = torch.randn(8, 256, 64, 64, generator=g).to(dev).contiguous(memory_format=torch.channels_last)

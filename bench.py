@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--gen-state", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's arithmetic (the headline metric, BASELINE.json configs[1]); "
+                         "bf16 = configs[2] (use with --batch 32): bf16 MFMA operands, fp32 accumulate")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +121,7 @@ def main():
     from munit_amd.trainer import MUNIT_Trainer
 
     hp = bench_hp(args.size, args.batch, args.gen_state)
+    hp["precision"] = args.precision
     torch.manual_seed(1234)
     trainer = MUNIT_Trainer(hp)
     trainer.to(dev)
@@ -155,14 +159,16 @@ def main():
         "metric": "images/sec (gen_update+dis_update) @%dx%d bs=%d" % (args.size, args.size, args.batch),
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "config_256.yaml AdaINGen_double+MsImageDis dis_update+gen_update, %dx%d, "
-                               "per-GPU batch %d, fp32" % (args.size, args.size, args.batch),
+                               "per-GPU batch %d, %s" % (args.size, args.size, args.batch,
+                                                         "fp32" if args.precision == "f32" else
+                                                         "bf16 MFMA operands / fp32 accumulate and storage"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "gen_state": args.gen_state, "loss_gen_total": round(loss_total, 5)},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.precision == "f32":
         step_flop = GFLOP_PER_PAIR_256 * 1e9 * (args.size / 256.0) ** 2 * args.batch
         ops.PROFILE = []
         for _ in range(2):

@@ -31,6 +31,7 @@ struct WgradParams {
   long long dy_off;
   int frame;  // GEMM rows enumerate only the 2-pixel border frame of the Ho x Wo output (see decode_pixel)
   unsigned x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST loader (0 when >= 2 GiB)
+  int bf16;                    // operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (FAST variants only)
 };
 
 // row index -> (sample, output row, output column); same enumeration as conv_igemm.hip
@@ -91,8 +92,21 @@ struct Frag<2> {
 // straight-line buffer loads with 32-bit offsets (invalid rows get an out-of-range offset and read as
 // zero), the pixel walk is a carry chain without divisions -- ~1/4 of the generic loader's VALU work,
 // which at 16 MFMAs per wave and step was the limiter.
-template <int BC, bool ALIGNED, bool FAST>
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 operand images (BF16 mode): [32 pixel rows][256 B = 128 channels], the 16-byte chunk ch of a row stored at
+// ch ^ (((row&3)<<2) | ((row>>2)&3)).  The contraction index (pixel) is the slow dimension, so the MFMA
+// operands (8 consecutive pixels of one channel per lane) are fetched with ds_read_b64_tr_b16, which hands
+// each lane a COLUMN of a 4-row x 16-channel block; this XOR keeps both those reads and the 8-byte stores
+// conflict-free (layout (b) of cdna_hip_programming.md T10).
+__device__ inline int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int BC, bool ALIGNED, bool FAST, bool BF16 = false>
 __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
+  static_assert(!BF16 || FAST, "the bf16 variant uses the FAST loader");
   // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64): every wave
   // owns eight 16x16 accumulators either way (4 cout tiles x 2 k tiles, or 2 x 4).
   constexpr int WKT = BC == 128 ? 128 : 256;
@@ -279,7 +293,28 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
       rd[i] = v;
     }
   };
+  constexpr int NXI = WKT / 128;              // X images per buffer (BF16 mode); image 0 of a buffer is dy
+  char* const img_base = reinterpret_cast<char*>(Xs);
   auto store_tiles = [&](int buf) {
+    if constexpr (BF16) {
+      char* ib = img_base + buf * ((1 + NXI) * 8192);
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) {
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rx[i][e];
+        const int quad = xq & 31;
+        *reinterpret_cast<bf16x4*>(ib + (1 + (xq >> 5)) * 8192 + img_off(xr0 + XRPT * i, quad >> 1) + 8 * (quad & 1)) = h;
+      }
+#pragma unroll
+      for (int i = 0; i < DROWS; ++i) {
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rd[i][e];
+        *reinterpret_cast<bf16x4*>(ib + img_off(dr0 + DRPT * i, dq >> 1) + 8 * (dq & 1)) = h;
+      }
+      return;
+    }
     float* Xd = Xs + buf * (WP * WKT);
     float* Dd = Ds + buf * (WP * BC);
 #pragma unroll
@@ -307,7 +342,38 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   // 16 of the 32 pixels of a step: wide LDS reads for GB pixel groups at a time, then GB * MT * NT MFMAs
   // (the generic loader keeps more per-row state in registers and takes smaller batches)
   constexpr int GB = (FAST || BC == 128) ? 4 : 2;
+  // BF16: operand of the 16-channel tile starting at channel c0 of image `im`: pixels 8*fg .. 8*fg+7 of channel
+  // c0 + fj, from two transposed 4x16 block reads (lane 4q+p of a 16-lane group addresses row q, channels 4p..4p+3)
+  auto tr_frag = [&](const char* im, int c0) -> bf16x8 {
+    const int q = fj >> 2, pp = lane & 3;
+    const int ch = (c0 >> 3) + (pp >> 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(im + img_off(8 * fg + q, ch) + 8 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(im + img_off(8 * fg + 4 + q, ch) + 8 * (pp & 1)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
   auto compute_half = [&](int buf, int p0) {
+    if constexpr (BF16) {
+      // one v_mfma_f32_16x16x32_bf16 per tile pair contracts all 32 pixels of the step; half 0 / 1 = first / second half of the cout tiles
+      const char* ib = img_base + buf * ((1 + NXI) * 8192);
+      bf16x8 hb[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int col = wn * WK + 16 * u;
+        hb[u] = tr_frag(ib + (1 + (col >> 7)) * 8192, col & 127);
+      }
+      const int h = p0 ? 1 : 0;
+#pragma unroll
+      for (int t = h * (MT / 2); t < (h + 1) * (MT / 2); ++t) {
+        const bf16x8 ha = tr_frag(ib, wm * WC + 16 * t);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[u], acc[t][u], 0, 0, 0);
+      }
+      return;
+    }
     const float* Dc = Ds + buf * (WP * BC);
     const float* Xc = Xs + buf * (WP * WKT);
 #pragma unroll
@@ -347,9 +413,16 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
     }
     compute_half(cur, WP / 2);
     if (do_bias && tid < BC) {
-      const float* Dc = Ds + cur * (WP * BC);
+      if constexpr (BF16) {
+        const char* ib = img_base + cur * ((1 + NXI) * 8192);
 #pragma unroll 8
-      for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
+        for (int r = 0; r < WP; ++r)
+          bsum += (float)*reinterpret_cast<const __bf16*>(ib + img_off(r, tid >> 3) + 2 * (tid & 7));
+      } else {
+        const float* Dc = Ds + cur * (WP * BC);
+#pragma unroll 8
+        for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -358,6 +431,22 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   // ---- write the partial tile: slab[split][co][k] ----
   // accumulator (t, u), register r of lane (fj, fg): cout row MT*(4*fg + r) + t, k column NT*fj + u
   float* out = p.slab + (long long)split * p.Cout * p.Ktot;
+  if constexpr (BF16) {
+    // natural C/D map: accumulator (t, u), register r of lane (fj, fg) = cout row 16t + 4*fg + r, k column 16u + fj
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * WC + 16 * t + 4 * fg + r;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const int k = kc0 + wn * WK + 16 * u + fj;
+          if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[t][u][r];
+        }
+      }
+    if (do_bias && tid < BC && co0 + tid < p.Cout) p.bias_slab[(long long)split * p.Cout + co0 + tid] = bsum;
+    return;
+  }
   const int k_base = kc0 + wn * WK + NT * fj;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -490,7 +579,10 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
                     (long long)p.B * p.H * p.W < (1ll << 23) && !getenv("MUNIT_DEBUG_NO_FAST_WGRAD");
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
-  if (pl.bc == 64) {
+  if (fast && p.bf16) {
+    if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, true>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, true>), grid, dim3(WTHR), 0, st, p);
+  } else if (pl.bc == 64) {
     if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true>), grid, dim3(WTHR), 0, st, p);
     else if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, false>), grid, dim3(WTHR), 0, st, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, false, false>), grid, dim3(WTHR), 0, st, p);
@@ -566,6 +658,7 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
   p.Ktot = d->KH * d->KW * d->Cin; p.M = d->B * Ho * Wo;
   p.dy_sw = d->Cout; p.dy_sh = (long long)Wo * d->Cout; p.dy_sb = (long long)Ho * Wo * d->Cout; p.dy_off = 0;
   if (subpixel_wgrad_ok(d)) {

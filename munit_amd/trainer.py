@@ -168,6 +168,11 @@ class MUNIT_Trainer(nn.Module):
         self.full_adaptation = hyperparameters["adaptation"]["full_adaptation"] == 1
         self.hyperparameters = hyperparameters
         self.iterations = 0
+        # build extension (no reference counterpart): `precision: bf16` = BASELINE.json config #3 -- the conv /
+        # linear contractions multiply bf16-rounded operands with fp32 accumulation; tensors, norm statistics,
+        # losses and the optimizer stay fp32.  Default: the reference's fp32 arithmetic.
+        self.precision = hyperparameters.get("precision", "f32")
+        ops.set_compute(self.precision)
 
         optimizer = FusedExtraAdam if "extra" in hyperparameters["optimizer"] else FusedAdam  # trainer.py:41-45
         self.domain_classif_ab = hyperparameters.get("domain_adv_w", 0) > 0
@@ -287,6 +292,7 @@ class MUNIT_Trainer(nn.Module):
 
     def forward(self, x_a, x_b):
         """trainer.py:307-334."""
+        ops.set_compute(self.precision)
         self.eval()
         with torch.no_grad():
             s_a, s_b = self.s_a.to(x_a.device), self.s_b.to(x_a.device)
@@ -311,6 +317,7 @@ class MUNIT_Trainer(nn.Module):
     # ---- gen_update (trainer.py:336-561) -----------------------------------------------
     def gen_update(self, x_a, x_b, hyperparameters, mask_a=None, mask_b=None, comet_exp=None, synth=False,
                    semantic_gt_a=None, semantic_gt_b=None):
+        ops.set_compute(self.precision)
         hp = hyperparameters
         if synth and hp.get("recon_synth_w", 0) > 0:
             raise NotImplementedError("munit_amd: synthetic-pair reconstruction loss is outside the hot path")
@@ -390,6 +397,7 @@ class MUNIT_Trainer(nn.Module):
 
     # ---- dis_update (trainer.py:1133-1190) ---------------------------------------------
     def dis_update(self, x_a, x_b, hyperparameters, comet_exp=None):
+        ops.set_compute(self.precision)
         hp = hyperparameters
         self.dis_opt.zero_grad()
         s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
@@ -434,6 +442,7 @@ class MUNIT_Trainer(nn.Module):
 
     # ---- sampling (trainer.py:773-928, core outputs only) -------------------------------
     def sample(self, x_a, x_b):
+        ops.set_compute(self.precision)
         self.eval()
         outs = [[] for _ in range(6)]
         with torch.no_grad():

@@ -93,3 +93,78 @@ def test_bf16_mode_is_off_by_default_and_validated():
         ops.set_compute("fp8")
     ops.set_compute("bf16")
     assert ops.get_compute() == "bf16"
+
+
+WGRAD_CASES = [
+    # cin, cout, k, stride, pad, pad_type, ups, B, H, W
+    (256, 256, 3, 1, 1, "reflect", 0, 2, 8, 8),       # 128x128 tile
+    (64, 128, 4, 2, 1, "reflect", 0, 2, 16, 16),
+    (128, 64, 3, 1, 1, "zero", 0, 2, 9, 11),           # Cout <= 64: 64x256 tile, two X images
+    (256, 128, 5, 1, 2, "reflect", 1, 2, 6, 8),        # sub-pixel phases (bf16) + frame (fp32)
+    (32, 48, 3, 1, 1, "zero", 0, 3, 33, 17),           # partial tiles, several pixel splits
+    (256, 512, 4, 2, 1, "reflect", 0, 2, 4, 4),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "c%d-%d_k%ds%d_u%d" % (c[0], c[1], c[2], c[3], c[6]))
+def test_conv_bf16_wgrad(case):
+    """dw / db of the bf16 backward-weight kernel = fp64 gradient on bf16-rounded x and dy (fp32 accumulation)."""
+    from munit_amd import ops
+    cin, cout, k, stride, pad, pt, ups, B, H, W = case
+    x = rnd((B, cin, H, W), 11)
+    w = rnd((cout, cin, k, k), 12, 0.05)
+    xq = r16(x)
+    wr = w.clone().requires_grad_(True)
+    br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    src = O.upsample2(xq) if ups else xq
+    y = O.conv_block(src, wr, br, stride, pad, pt, None, "none")
+    dy = rnd(tuple(y.shape), 13)
+    y.backward(r16(dy))
+    xd = x.float().to(dev()).contiguous(memory_format=torch.channels_last)
+    dyd = dy.float().to(dev()).contiguous(memory_format=torch.channels_last)
+    dw, db = ops.conv2d_wgrad_raw(xd, dyd, tuple(w.shape), stride, pad, pt, bool(ups))
+    tol = SHARP if not ups else 5e-3      # the frame pixels of the sub-pixel form are computed in fp32 from unrounded data
+    assert nerr(dw, wr.grad) <= tol, ("dw", nerr(dw, wr.grad))
+    assert nerr(db, br.grad) <= tol, ("db", nerr(db, br.grad))
+
+
+def test_step_bf16_tracks_fp32_step():
+    """One dis_update + gen_update in bf16-compute mode against the same step in fp32 mode (same weights, same
+    batch): every loss within 2e-2 relative (the stated tolerance of config #3), weights moved the same way."""
+    from munit_amd import ops
+    from munit_amd.trainer import MUNIT_Trainer
+    from tests.parity import l2err
+    import bench
+    size, batch = 64, 2
+    x_a, x_b, m_a, m_b = (t.to(dev()) for t in bench.make_batch(batch, size))
+    out = {}
+    for prec in ("f32", "bf16"):
+        hp = bench.bench_hp(size, batch)
+        hp["precision"] = prec
+        torch.manual_seed(1234)
+        tr = MUNIT_Trainer(hp)
+        tr.to(dev())
+        torch.manual_seed(5)
+        tr.dis_update(x_a, x_b, hp)
+        tr.gen_update(x_a, x_b, hp, m_a, m_b)
+        names = [n for n in vars(tr) if n.startswith("loss_")]
+        out[prec] = ({n: float(getattr(tr, n)) for n in names},
+                     {k: v.detach().clone() for k, v in tr.gen.state_dict().items() if v.dtype == torch.float32})
+        assert ops.get_compute() == prec
+    ops.set_compute("bf16")
+    lf, lb = out["f32"][0], out["bf16"][0]
+    assert set(lf) == set(lb) and len(lf) >= 10
+    for n in lf:
+        assert abs(lb[n] - lf[n]) <= 2e-2 * max(abs(lf[n]), 1e-3), (n, lf[n], lb[n])
+    # Adam's first step is sign-like (|dw| = lr): the two runs must agree on the direction for almost all weights
+    wf, wb = out["f32"][1], out["bf16"][1]
+    agree, total = 0, 0
+    torch.manual_seed(1234)
+    init = MUNIT_Trainer(bench.bench_hp(size, batch)).gen.state_dict()
+    for k in wf:
+        d0 = (wf[k].cpu() - init[k]).flatten()
+        d1 = (wb[k].cpu() - init[k]).flatten()
+        nz = d0.abs() > 0
+        agree += int((torch.sign(d0[nz]) == torch.sign(d1[nz])).sum())
+        total += int(nz.sum())
+    assert total > 1e6 and agree / total > 0.9, (agree, total)

@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gen-state", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16", "f32x3"], default="f32",
                     help="f32 = the reference's arithmetic (the headline metric, BASELINE.json configs[1]); "
                          "bf16 = configs[2] (use with --batch 32): bf16 MFMA operands, fp32 accumulate")
     args = ap.parse_args()
@@ -162,8 +162,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "config_256.yaml AdaINGen_double+MsImageDis dis_update+gen_update, %dx%d, "
                                "per-GPU batch %d, %s" % (args.size, args.size, args.batch,
-                                                         "fp32" if args.precision == "f32" else
-                                                         "bf16 MFMA operands / fp32 accumulate and storage"),
+                                                         {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
+                                                          "f32x3": "fp32 via exact 3-way bf16 split (6 product terms), fp32 accumulate"}[args.precision]),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "gen_state": args.gen_state, "loss_gen_total": round(loss_total, 5)},
     }

@@ -38,8 +38,11 @@ enum { MUNIT_PAD_ZERO = 0, MUNIT_PAD_REFLECT = 1 };
 /* MUNIT_COMPUTE_F32: exact fp32 MFMA (the reference's arithmetic).  MUNIT_COMPUTE_BF16: operands rounded to
  * bf16 (nearest-even) as they are staged into LDS, v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the
  * bf16 mode of BASELINE.json config #3, a build extension with no reference counterpart.  Layers whose
- * channel count is not a multiple of 32 (the 3-channel image layers) stay fp32 in both modes. */
-enum { MUNIT_COMPUTE_F32 = 0, MUNIT_COMPUTE_BF16 = 1 };
+ * channel count is not a multiple of 32 (the 3-channel image layers) stay fp32 in both modes.
+ * MUNIT_COMPUTE_F32X3: fp32 accuracy on the bf16 matrix pipe -- each fp32 operand is split exactly into three
+ * bf16 values (a = a0 + a1 + a2) and the six products a_i*b_j with i + j <= 2 are accumulated in fp32; the
+ * dropped terms are <= 2^-24 |a||b|, below the rounding of an fp32 FMA chain.  Opt-in. */
+enum { MUNIT_COMPUTE_F32 = 0, MUNIT_COMPUTE_BF16 = 1, MUNIT_COMPUTE_F32X3 = 2 };
 
 int munit_version(void);
 const char* munit_last_error(void);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MUNIT_HIP_LIB") or os.path.join(_HERE, "libmunit_hip.
 
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 PAD = {"zero": 0, "reflect": 1}
-COMPUTE = {"f32": 0, "bf16": 1}
+COMPUTE = {"f32": 0, "bf16": 1, "f32x3": 2}
 
 
 class ConvDesc(Structure):

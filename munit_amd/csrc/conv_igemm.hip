@@ -50,7 +50,7 @@ struct IgemmParams {
   // slab[(phase*ksplit + z)][M][Cout] and splitk_epilogue_kernel sums them in order (+bias, act)
   int ksplit, kt_per_split;
   float* slab;
-  int bf16;  // operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (aligned variants only)
+  int ct;    // compute type (aligned variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3 split
 };
 
 // row index -> (sample, output row, output column)
@@ -128,8 +128,16 @@ __device__ inline int cand_at(uint2 v, int a) {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BN, bool ALIGNED, int ROLE, bool BF16 = false>
+// CT (compute type): 0 = fp32 MFMA; 1 = bf16 operands; 2 = "f32x3": every fp32 operand is split exactly into
+// three bf16 planes a = a0 + a1 + a2 (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)) and the six
+// products a_i * b_j with i + j <= 2 are accumulated in fp32.  The dropped terms are <= 2^-24 |a||b|; measured
+// against fp64 the result is as accurate as the fp32 FMA chain (truncation 6e-9 vs 4e-7 accumulation error,
+// K = 2304).  Six bf16 MFMAs cost 6/16 of one fp32 MFMA step.  Three planes are single-buffered in LDS (two
+// barriers per K-tile) to keep two blocks per CU.
+template <int BN, bool ALIGNED, int ROLE, int CT = 0>
 __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
+  constexpr bool BF16 = CT != 0;
+  constexpr int NPL = CT == 2 ? 3 : 1;     // bf16 planes per operand
   static_assert(!BF16 || ALIGNED, "bf16 operands need Cin % 32 == 0");
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
   // waves gather (measured MfmaUtil 73 % with 4 waves / 210 registers -> see profiles/).
@@ -358,28 +366,32 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   // position c ^ F[(row>>2)&3], F = {0,2,3,1}, which makes the fragment ds_read_b128 conflict-free
   // (every 16-lane service group then touches 16 distinct (row&3, position) pairs = all 64 banks).
   __bf16* const Ah = reinterpret_cast<__bf16*>(smem);
-  __bf16* const Bh = Ah + 2 * BM * 32;
+  __bf16* const Bh = Ah + (CT == 2 ? 3 : 2) * BM * 32;   // bf16: two buffers; f32x3: three planes, one buffer
   const int st_swz = (0x78 >> (2 * ((r0 >> 2) & 3))) & 3;     // RSTEP % 16 == 0: the same for all rows of a thread
   const int st_col = (((c4 >> 1) ^ st_swz) * 8) + (c4 & 1) * 4;  // bf16 index inside the row
   auto store_tile = [&](int buf) {
     if constexpr (BF16) {
-      __bf16* Ad = Ah + buf * (BM * 32);
-      __bf16* Bd = Bh + buf * (BN * 32);
+      // plane pl of buffer buf: A at Ah + (buf*NPL + pl) * BM*32, B at Bh + (buf*NPL + pl) * BN*32
+      auto put = [&](__bf16* base, int plane_elems, int row, f32x4 v) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4*>(&base[pl * plane_elems + row * 32 + st_col]) = h;
+          if (pl + 1 < NPL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] -= (float)h[e];   // exact: the remainder fits fp32
+          }
+        }
+      };
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         if constexpr (ROLE == 2) ra[i] += rx[i];
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e];
-        *reinterpret_cast<bf16x4*>(&Ad[(r0 + RSTEP * i) * 32 + st_col]) = h;
+        put(Ah + buf * NPL * (BM * 32), BM * 32, r0 + RSTEP * i, ra[i]);
       }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[i][e];
-        *reinterpret_cast<bf16x4*>(&Bd[(r0 + RSTEP * i) * 32 + st_col]) = h;
-      }
+      for (int i = 0; i < BROWS; ++i) put(Bh + buf * NPL * (BN * 32), BN * 32, r0 + RSTEP * i, rb[i]);
       return;
     }
     float* Ad = As + buf * (BM * LDS_LD);
@@ -411,19 +423,30 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   const int fr_col = (((lane >> 4) ^ ((0x78 >> (2 * ((frag_row >> 2) & 3))) & 3)) * 8);   // bf16 fragment chunk
   auto compute_half = [&](int buf, int kg) {
     if constexpr (BF16) {
-      // one v_mfma_f32_16x16x32_bf16 per tile pair covers the whole 32-deep K-tile: half kg takes half of the row tiles
-      const __bf16* Ac = Ah + buf * (BM * 32);
-      const __bf16* Bc = Bh + buf * (BN * 32);
-      bf16x8 hb[NT];
+      // one v_mfma_f32_16x16x32_bf16 per tile pair (and per product term) covers the whole 32-deep K-tile: half
+      // kg takes half of the row tiles
+      const __bf16* Ac = Ah + buf * NPL * (BM * 32);
+      const __bf16* Bc = Bh + buf * NPL * (BN * 32);
+      bf16x8 hb[NPL][NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        hb[nt] = *reinterpret_cast<const bf16x8*>(&Bc[(wn * WN + nt * 16 + frag_row) * 32 + fr_col]);
-#pragma unroll
-      for (int mt = kg * (MT / 2); mt < (kg + 1) * (MT / 2); ++mt) {
-        const bf16x8 ha = *reinterpret_cast<const bf16x8*>(&Ac[(wm * WM + mt * 16 + frag_row) * 32 + fr_col]);
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[nt], acc[mt][nt], 0, 0, 0);
+          hb[pl][nt] = *reinterpret_cast<const bf16x8*>(&Bc[pl * (BN * 32) + (wn * WN + nt * 16 + frag_row) * 32 + fr_col]);
+#pragma unroll
+      for (int mt = kg * (MT / 2); mt < (kg + 1) * (MT / 2); ++mt) {
+        bf16x8 ha[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          ha[pl] = *reinterpret_cast<const bf16x8*>(&Ac[pl * (BM * 32) + (wm * WM + mt * 16 + frag_row) * 32 + fr_col]);
+        // product terms a_i * b_j, i + j <= NPL - 1, smallest first
+#pragma unroll
+        for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+          for (int i = 0; i <= sum; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[i], hb[sum - i][nt], acc[mt][nt], 0, 0, 0);
       }
       return;
     }
@@ -457,28 +480,43 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   // passed the barrier that ended tile t-1 and nobody reads that buffer before the next barrier -- and the
   // loads of tile t+2 are issued into the freed registers.  One barrier per K-tile.
   const int nk = kt_end - kt_begin;
-  if (nk > 0) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-  if (nk > 1) load_tile(kt_begin + 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    compute_half(cur, 0);
-    if (kt + 1 < nk) {
+  if constexpr (CT == 2) {
+    // three planes, one LDS buffer: barrier, split the registers (tile kt) into the planes, issue the loads of
+    // tile kt+1, barrier, multiply.  The other resident block covers the store phase.
+    if (nk > 0) load_tile(kt_begin);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      store_tile(0);
+      if (kt + 1 < nk) load_tile(kt_begin + kt + 1);
+      __syncthreads();
+      compute_half(0, 0);
+      compute_half(0, 1);
+    }
+    __syncthreads();
+  } else {
+    if (nk > 0) {
+      load_tile(kt_begin);
+      store_tile(0);
+    }
+    __syncthreads();
+    if (nk > 1) load_tile(kt_begin + 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      compute_half(cur, 0);
+      if (kt + 1 < nk) {
 #ifndef ABL_NOLDSW
-      store_tile(cur ^ 1);
+        store_tile(cur ^ 1);
 #endif
 #ifndef ABL_NOGLOBAL
-      if (kt + 2 < nk) load_tile(kt_begin + kt + 2);
+        if (kt + 2 < nk) load_tile(kt_begin + kt + 2);
+#endif
+      }
+      if constexpr (ROLE == 2) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads below the gather (registers)
+      compute_half(cur, 1);
+#ifndef ABL_NOBAR
+      __syncthreads();
 #endif
     }
-    if constexpr (ROLE == 2) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads below the gather (registers)
-    compute_half(cur, 1);
-#ifndef ABL_NOBAR
-    __syncthreads();
-#endif
   }
 
   // ---- epilogue ----
@@ -743,18 +781,22 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       return MUNIT_ERR_ARG;
     }
     if (bn == 64) {
-      if (p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, true>), grid, block, 0, st, q);
+      if (p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, 2>), grid, block, 0, st, q);
+      else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2>), grid, block, 0, st, q);
     } else {
-      if (p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, true>), grid, block, 0, st, q);
+      if (p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 2>), grid, block, 0, st, q);
+      else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
     }
   } else if (bn == 64) {
-    if (aligned && p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, true>), grid, block, 0, st, q);
+    if (aligned && p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 2>), grid, block, 0, st, q);
+    else if (aligned && p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 1>), grid, block, 0, st, q);
     else if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<64, false, ROLE>), grid, block, 0, st, q);
   } else {
-    if (aligned && p.bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, true>), grid, block, 0, st, q);
+    if (aligned && p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 2>), grid, block, 0, st, q);
+    else if (aligned && p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 1>), grid, block, 0, st, q);
     else if (aligned) hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, false, ROLE>), grid, block, 0, st, q);
   }
@@ -773,7 +815,7 @@ int check_desc(const munit_conv_desc* d) {
   MUNIT_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad dims");
   MUNIT_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
   MUNIT_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv: upsample must be 0 or 1");
-  MUNIT_CHECK_ARG(d->compute == MUNIT_COMPUTE_F32 || d->compute == MUNIT_COMPUTE_BF16, "conv: bad compute mode %d", d->compute);
+  MUNIT_CHECK_ARG(d->compute >= MUNIT_COMPUTE_F32 && d->compute <= MUNIT_COMPUTE_F32X3, "conv: bad compute mode %d", d->compute);
   MUNIT_CHECK_ARG(d->pad_mode == MUNIT_PAD_ZERO || d->pad_mode == MUNIT_PAD_REFLECT, "conv: bad pad mode");
   const int Hu = d->H << d->upsample, Wu = d->W << d->upsample;
   if (d->pad_mode == MUNIT_PAD_REFLECT)
@@ -836,7 +878,7 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
   p.y_sb = (long long)Ho * Wo * d->Cout;
   p.M = d->B * Ho * Wo;
   p.act = d->act; p.slope = d->slope;
-  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
+  p.ct = d->compute;
   p.ps = 1;
   if (subpixel_ok(d)) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
@@ -996,8 +1038,8 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     p.y_sb = (long long)d->H * d->W * d->Cin;
     p.M = d->B * d->H * d->W;
     p.act = MUNIT_ACT_NONE; p.slope = 0.f;
-  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
-    p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
+  p.ct = d->compute;
+    p.ct = d->compute;
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
@@ -1026,7 +1068,7 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
   p.y_sb = (long long)pl.Hq * pl.Wq * d->Cin;
   p.M = d->B * p.Ho * p.Wo;
   p.act = MUNIT_ACT_NONE; p.slope = 0.f;
-  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
+  p.ct = d->compute;
   p.ps = pl.ps;
   p.w_phase = (long long)d->Cin * p.Ktot;
   p.y_phase_row = (long long)pl.Wq * d->Cin;

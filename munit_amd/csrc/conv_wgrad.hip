@@ -31,7 +31,7 @@ struct WgradParams {
   long long dy_off;
   int frame;  // GEMM rows enumerate only the 2-pixel border frame of the Ho x Wo output (see decode_pixel)
   unsigned x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST loader (0 when >= 2 GiB)
-  int bf16;                    // operands rounded to bf16 in LDS, v_mfma_f32_16x16x32_bf16 (FAST variants only)
+  int ct;                      // compute type (FAST variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3
 };
 
 // row index -> (sample, output row, output column); same enumeration as conv_igemm.hip
@@ -104,9 +104,13 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 // conflict-free (layout (b) of cdna_hip_programming.md T10).
 __device__ inline int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-template <int BC, bool ALIGNED, bool FAST, bool BF16 = false>
+// CT: 0 fp32 MFMA, 1 bf16 operands, 2 f32x3 (three exact bf16 planes per operand, six product terms; see
+// conv_igemm.hip).  f32x3 keeps one LDS buffer of 3 planes (two barriers per step).
+template <int BC, bool ALIGNED, bool FAST, int CT = 0>
 __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
-  static_assert(!BF16 || FAST, "the bf16 variant uses the FAST loader");
+  constexpr bool BF16 = CT != 0;
+  constexpr int NPL = CT == 2 ? 3 : 1;
+  static_assert(!BF16 || FAST, "the bf16 variants use the FAST loader");
   // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64): every wave
   // owns eight 16x16 accumulators either way (4 cout tiles x 2 k tiles, or 2 x 4).
   constexpr int WKT = BC == 128 ? 128 : 256;
@@ -123,8 +127,10 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   constexpr int SWZ_D = MT == 2 ? 32 : 0;
   constexpr int SWZ_X = NT == 2 ? 32 : 0;
   static_assert(XRPT % 2 == 0 && DRPT % 2 == 0, "row parity of a loader thread must not change between passes");
-  __shared__ __attribute__((aligned(16))) float Ds[2 * WP * BC];   // double-buffered: one barrier per step
-  __shared__ __attribute__((aligned(16))) float Xs[2 * WP * WKT];
+  // one allocation: fp32 mode carves double-buffered dy / x tiles (one barrier per step), the bf16 modes their images
+  __shared__ __attribute__((aligned(16))) float smem[2 * WP * BC + 2 * WP * WKT];
+  float* const Ds = smem;
+  float* const Xs = smem + 2 * WP * BC;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -294,25 +300,32 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
     }
   };
   constexpr int NXI = WKT / 128;              // X images per buffer (BF16 mode); image 0 of a buffer is dy
-  char* const img_base = reinterpret_cast<char*>(Xs);
+  static_assert((CT == 2 ? 3 : 2) * (1 + NXI) * 8192 <= (int)sizeof(float) * (2 * WP * BC + 2 * WP * WKT), "bf16 images must fit the LDS allocation");
+  char* const img_base = reinterpret_cast<char*>(smem);
   auto store_tiles = [&](int buf) {
     if constexpr (BF16) {
-      char* ib = img_base + buf * ((1 + NXI) * 8192);
+      // buffer = NPL planes x (1 dy image + NXI x images) x 8 KiB
+      char* ib = img_base + buf * (NPL * (1 + NXI) * 8192);
+      auto put = [&](char* dst, f32x4 v) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4*>(dst + pl * ((1 + NXI) * 8192)) = h;
+          if (pl + 1 < NPL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] -= (float)h[e];
+          }
+        }
+      };
 #pragma unroll
       for (int i = 0; i < XROWS; ++i) {
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rx[i][e];
         const int quad = xq & 31;
-        *reinterpret_cast<bf16x4*>(ib + (1 + (xq >> 5)) * 8192 + img_off(xr0 + XRPT * i, quad >> 1) + 8 * (quad & 1)) = h;
+        put(ib + (1 + (xq >> 5)) * 8192 + img_off(xr0 + XRPT * i, quad >> 1) + 8 * (quad & 1), rx[i]);
       }
 #pragma unroll
-      for (int i = 0; i < DROWS; ++i) {
-        bf16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (__bf16)rd[i][e];
-        *reinterpret_cast<bf16x4*>(ib + img_off(dr0 + DRPT * i, dq >> 1) + 8 * (dq & 1)) = h;
-      }
+      for (int i = 0; i < DROWS; ++i) put(ib + img_off(dr0 + DRPT * i, dq >> 1) + 8 * (dq & 1), rd[i]);
       return;
     }
     float* Xd = Xs + buf * (WP * WKT);
@@ -356,21 +369,53 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   };
   auto compute_half = [&](int buf, int p0) {
     if constexpr (BF16) {
-      // one v_mfma_f32_16x16x32_bf16 per tile pair contracts all 32 pixels of the step; half 0 / 1 = first / second half of the cout tiles
-      const char* ib = img_base + buf * ((1 + NXI) * 8192);
-      bf16x8 hb[NT];
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const int col = wn * WK + 16 * u;
-        hb[u] = tr_frag(ib + (1 + (col >> 7)) * 8192, col & 127);
-      }
+      // one v_mfma_f32_16x16x32_bf16 per tile pair (and product term) contracts all 32 pixels of the step; half
+      // 0 / 1 = first / second half of the tiles of the operand that is NOT kept resident
+      const char* ib = img_base + buf * (NPL * (1 + NXI) * 8192);
+      constexpr int PLB = (1 + NXI) * 8192;
       const int h = p0 ? 1 : 0;
+      if constexpr (NT <= MT) {   // keep the k-side fragments resident, stream the cout tiles
+        bf16x8 hb[NPL][NT];
 #pragma unroll
-      for (int t = h * (MT / 2); t < (h + 1) * (MT / 2); ++t) {
-        const bf16x8 ha = tr_frag(ib, wm * WC + 16 * t);
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
-          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[u], acc[t][u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u) {
+            const int col = wn * WK + 16 * u;
+            hb[pl][u] = tr_frag(ib + pl * PLB + (1 + (col >> 7)) * 8192, col & 127);
+          }
+#pragma unroll
+        for (int t = h * (MT / 2); t < (h + 1) * (MT / 2); ++t) {
+          bf16x8 ha[NPL];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) ha[pl] = tr_frag(ib + pl * PLB, wm * WC + 16 * t);
+#pragma unroll
+          for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int i = 0; i <= sum; ++i)
+#pragma unroll
+              for (int u = 0; u < NT; ++u)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[i], hb[sum - i][u], acc[t][u], 0, 0, 0);
+        }
+      } else {                    // Cout <= 64 tile: two cout tiles resident, stream the four k tiles
+        bf16x8 ha[NPL][MT];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) ha[pl][t] = tr_frag(ib + pl * PLB, wm * WC + 16 * t);
+#pragma unroll
+        for (int u = h * (NT / 2); u < (h + 1) * (NT / 2); ++u) {
+          const int col = wn * WK + 16 * u;
+          bf16x8 hb[NPL];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) hb[pl] = tr_frag(ib + pl * PLB + (1 + (col >> 7)) * 8192, col & 127);
+#pragma unroll
+          for (int sum = NPL - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int i = 0; i <= sum; ++i)
+#pragma unroll
+              for (int t = 0; t < MT; ++t)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[i][t], hb[sum - i], acc[t][u], 0, 0, 0);
+        }
       }
       return;
     }
@@ -398,34 +443,63 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
 
   // same pipeline as conv_igemm_kernel: registers hold step s+1 while step s is multiplied out of LDS
   // buffer s&1; half-way they are written to the other buffer and the loads of step s+2 are issued.
-  if (m_begin < m_end) {
-    load_tiles(m_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-  if (m_begin + WP < m_end) load_tiles(m_begin + WP);
-  int cur = 0;
-  for (int mb = m_begin; mb < m_end; mb += WP) {
-    compute_half(cur, 0);
-    if (mb + WP < m_end) {
-      store_tiles(cur ^ 1);
-      if (mb + 2 * WP < m_end) load_tiles(mb + 2 * WP);
-    }
-    compute_half(cur, WP / 2);
-    if (do_bias && tid < BC) {
-      if constexpr (BF16) {
-        const char* ib = img_base + cur * ((1 + NXI) * 8192);
+  if constexpr (CT == 2) {
+    // one buffer of three planes: barrier, split the registers into the planes, issue the next loads, barrier, multiply
+    if (m_begin < m_end) load_tiles(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += WP) {
+      __syncthreads();
+      store_tiles(0);
+      if (mb + WP < m_end) load_tiles(mb + WP);
+      __syncthreads();
+      compute_half(0, 0);
+      compute_half(0, WP / 2);
+      if (do_bias && tid < BC) {
+        const char* ib = img_base;
 #pragma unroll 8
-        for (int r = 0; r < WP; ++r)
-          bsum += (float)*reinterpret_cast<const __bf16*>(ib + img_off(r, tid >> 3) + 2 * (tid & 7));
-      } else {
-        const float* Dc = Ds + cur * (WP * BC);
-#pragma unroll 8
-        for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
+        for (int r = 0; r < WP; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int pl = NPL - 1; pl >= 0; --pl)
+            v += (float)*reinterpret_cast<const __bf16*>(ib + pl * ((1 + NXI) * 8192) + img_off(r, tid >> 3) + 2 * (tid & 7));
+          bsum += v;
+        }
       }
     }
+  } else {
+    if (m_begin < m_end) {
+      load_tiles(m_begin);
+      store_tiles(0);
+    }
     __syncthreads();
-    cur ^= 1;
+    if (m_begin + WP < m_end) load_tiles(m_begin + WP);
+    int cur = 0;
+    for (int mb = m_begin; mb < m_end; mb += WP) {
+      compute_half(cur, 0);
+      if (mb + WP < m_end) {
+        store_tiles(cur ^ 1);
+        if (mb + 2 * WP < m_end) load_tiles(mb + 2 * WP);
+      }
+      compute_half(cur, WP / 2);
+      if (do_bias && tid < BC) {
+        if constexpr (BF16) {
+          const char* ib = img_base + cur * (NPL * (1 + NXI) * 8192);
+  #pragma unroll 8
+          for (int r = 0; r < WP; ++r) {
+            float v = 0.f;
+  #pragma unroll
+            for (int pl = NPL - 1; pl >= 0; --pl)   // planes summed small to large: reconstructs the fp32 value exactly
+              v += (float)*reinterpret_cast<const __bf16*>(ib + pl * ((1 + NXI) * 8192) + img_off(r, tid >> 3) + 2 * (tid & 7));
+            bsum += v;
+          }
+        } else {
+          const float* Dc = Ds + cur * (WP * BC);
+  #pragma unroll 8
+          for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ---- write the partial tile: slab[split][co][k] ----
@@ -579,9 +653,12 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
                     (long long)p.B * p.H * p.W < (1ll << 23) && !getenv("MUNIT_DEBUG_NO_FAST_WGRAD");
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
-  if (fast && p.bf16) {
-    if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, true>), grid, dim3(WTHR), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, true>), grid, dim3(WTHR), 0, st, p);
+  if (fast && p.ct == 1) {
+    if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 1>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 1>), grid, dim3(WTHR), 0, st, p);
+  } else if (fast && p.ct == 2) {
+    if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 2>), grid, dim3(WTHR), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 2>), grid, dim3(WTHR), 0, st, p);
   } else if (pl.bc == 64) {
     if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true>), grid, dim3(WTHR), 0, st, p);
     else if (aligned) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, false>), grid, dim3(WTHR), 0, st, p);
@@ -658,7 +735,7 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
-  p.bf16 = d->compute == MUNIT_COMPUTE_BF16;
+  p.ct = d->compute;
   p.Ktot = d->KH * d->KW * d->Cin; p.M = d->B * Ho * Wo;
   p.dy_sw = d->Cout; p.dy_sh = (long long)Wo * d->Cout; p.dy_sb = (long long)Ho * Wo * d->Cout; p.dy_off = 0;
   if (subpixel_wgrad_ok(d)) {

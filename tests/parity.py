@@ -109,7 +109,7 @@ def trainer_named_params(trainer):
 
 
 def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", oracle_dtype=torch.float64,
-                    step_size=2, check=True, optimizer="adam"):
+                    step_size=2, check=True, optimizer="adam", precision=None):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
     losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end)."""
@@ -118,6 +118,8 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
     hp = O.default_hp(size, batch, gen_state)
     hp["step_size"] = step_size
     hp["optimizer"] = optimizer
+    if precision is not None:
+        hp["precision"] = precision      # build extension: compute mode of the HIP trainer (the oracle ignores it)
     gen, dis_a, dis_b = oracle_states(hp, oracle_dtype)
     orc = O.OracleTrainer(hp, gen, dis_a, dis_b)
     tr = MUNIT_Trainer(dict(hp))

@@ -1,0 +1,60 @@
+"""GPU: the opt-in "f32x3" compute mode (fp32 operands split exactly into three bf16 planes, six product terms on
+the bf16 matrix pipe, fp32 accumulation) must pass the SAME parity tests at the SAME tolerances as the native
+fp32 MFMA kernels: every convolution case of test_gpu_ops.py (2e-5 forward, 1e-4 gradients vs the fp64 oracle)
+and the step-level parity against the oracle."""
+import pytest
+import torch
+
+from tests import test_gpu_ops as T
+from tests.parity import nerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def f32x3_mode():
+    from munit_amd import ops
+    ops.set_compute("f32x3")
+    yield
+    ops.set_compute("f32")
+
+
+@pytest.mark.parametrize("case", T.CONV_CASES, ids=lambda c: "c%d-%d_k%ds%d_%s_u%d_%s" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
+def test_conv_fwd_bwd_f32x3(case):
+    T.test_conv_fwd_bwd(case)
+
+
+def test_linear_f32x3():
+    T.test_linear()
+
+
+def test_resblock_size_accuracy_vs_native():
+    """Resblock-sized layer (K = 2304): error vs fp64 of the split kernels is not worse than the native fp32 kernels'."""
+    from munit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 32, 32, generator=g, dtype=torch.float64)
+    w = torch.randn(256, 256, 3, 3, generator=g, dtype=torch.float64) * 0.03
+    dy = torch.randn(2, 256, 32, 32, generator=g, dtype=torch.float64)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(torch.nn.functional.pad(xr, (1, 1, 1, 1), mode="reflect"), wr)
+    yr.backward(dy)
+    dev = torch.device("cuda:0")
+    errs = {}
+    for mode in ("f32", "f32x3"):
+        ops.set_compute(mode)
+        xd = x.float().to(dev).contiguous(memory_format=torch.channels_last)
+        wd = w.float().to(dev).contiguous(memory_format=torch.channels_last)
+        dyd = dy.float().to(dev).contiguous(memory_format=torch.channels_last)
+        y = ops.conv2d_fwd_raw(xd, wd, None, 1, 1, "reflect", False, "none")
+        dx = ops.conv2d_dgrad_raw(dyd, wd, tuple(x.shape), 1, 1, "reflect", False)
+        dw, _ = ops.conv2d_wgrad_raw(xd, dyd, tuple(w.shape), 1, 1, "reflect", False, want_bias=False)
+        errs[mode] = (nerr(y, yr), nerr(dx, xr.grad), nerr(dw, wr.grad))
+    for a, b in zip(errs["f32x3"], errs["f32"]):
+        assert a <= max(2.0 * b, 1e-6), errs
+    assert max(errs["f32x3"]) <= 5e-6, errs
+
+
+def test_step_parity_f32x3():
+    """dis_update + gen_update against the oracle with the tolerances of the fp32 step test."""
+    from tests.parity import run_step_parity
+    run_step_parity(size=64, batch=2, gen_state=1, iters=1, device=torch.device("cuda:0"), precision="f32x3")

@@ -57,6 +57,23 @@ def make_batch(batch, size, rank=0):
     return x_a, x_b, m_a, m_b
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md; bench.py cannot collect PMC itself).
+    Returns (bytes, source) or (None, None)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_hbm_mfma.txt")
+    try:
+        for line in open(path):
+            if line.startswith("conv_igemm_kernel<128, true, 0>") and "blocks=   512" in line:
+                f = line.split()
+                fetch = float(f[f.index("fetch") + 1])
+                write = float(f[f.index("write") + 1])
+                return (fetch + write) * 1e6, "profiles/r01_c_pmc_hbm_mfma.txt (512-block launches: %.0f MB read + %.0f MB written)" % (fetch, write)
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def cpu_baseline(size, seconds_budget=30.0):
     """The oracle's dis_update + gen_update on the host cores, batch 1 at the bench resolution."""
     from oracle import munit_oracle as O
@@ -182,7 +199,8 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic_bytes()[0],
+                "traffic_source": pmc_traffic_bytes()[1],
                 "kernel": "conv_igemm_kernel<128,true,fwd> (forward implicit-GEMM conv, Cout>64, Cin%32==0)",
                 "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                 "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),

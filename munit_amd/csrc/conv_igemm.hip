@@ -849,7 +849,9 @@ bool subpixel_ok(const munit_conv_desc* d) {
 extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
-  if (subpixel_ok(d)) return align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256);
+  if (subpixel_ok(d))   // merged phase weights + split-K slabs of the frame launch (few tiles, 25-tap K)
+    return align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256) +
+           splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1);
   if (munit_small_fwd_supported(d)) return 0;
   return splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
 }
@@ -912,7 +914,8 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
     if (rc) return rc;
     p.frame = 1;
     p.M = d->B * (4 * Wo + 4 * (Ho - 4));
-    return launch_igemm<0>(p, 1, st);
+    const size_t wc_bytes = align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256);
+    return launch_igemm<0>(p, 1, st, reinterpret_cast<char*>(ws) + wc_bytes, ws_bytes - wc_bytes);
   }
   return launch_igemm<0>(p, 1, st, ws, ws_bytes);
 }

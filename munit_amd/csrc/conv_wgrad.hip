@@ -566,6 +566,37 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
+// Same reduction for small outputs with many splits (the 3-channel first layers: 9.5 k outputs x 512 splits, where
+// one thread per output loops over every split for 130 us): 64 outputs per block, the splits dealt to 16 waves in
+// a fixed pattern and combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void slab_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                long long n, const float* __restrict__ bias_slab,
+                                                                float* __restrict__ db, int nb, int nsplit, float beta,
+                                                                float beta_b) {
+  __shared__ float red[16][64];
+  const int il = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const long long total = n + (db != nullptr ? nb : 0);
+  const long long i = (long long)blockIdx.x * 64 + il;
+  float s = 0.f;
+  if (i < total) {
+    if (i < n) {
+      for (int k = kg; k < nsplit; k += 16) s += slab[(long long)k * n + i];
+    } else {
+      const long long j = i - n;
+      for (int k = kg; k < nsplit; k += 16) s += bias_slab[(long long)k * nb + j];
+    }
+  }
+  red[kg][il] = s;
+  __syncthreads();
+  if (kg == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][il];
+    if (i < n) dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + t;
+    else db[i - n] = (beta_b != 0.f ? beta_b * db[i - n] : 0.f) + t;
+  }
+}
+
 // resident 512-thread blocks per CU of each instantiation (occupancy query, cached; 2 when unknown)
 int wgrad_blocks_per_cu(int bc, bool aligned) {
   static int cache[2][2] = {{0, 0}, {0, 0}};
@@ -670,6 +701,12 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   }
   MUNIT_CHECK_LAUNCH("conv_wgrad");
   const long long n = (long long)p.Cout * p.Ktot;
+  if (pl.nsplit >= 32 && n + p.Cout <= 64 * 2048) {
+    hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(n + p.Cout, 64)), dim3(1024), 0, st, p.slab, dw, n,
+                       p.bias_slab, db, p.Cout, pl.nsplit, beta, beta_b);
+    MUNIT_CHECK_LAUNCH("slab_reduce_wide");
+    return MUNIT_OK;
+  }
   const int blocks = (int)std::min<long long>((n + p.Cout + 255) / 256, 4096);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, n, p.bias_slab, db, p.Cout,
                      pl.nsplit, beta, beta_b);

@@ -644,6 +644,22 @@ __global__ void upw_scatter_kernel(const float* __restrict__ dwc, float* __restr
   }
 }
 
+// 3-channel inputs (the image layers): x is re-laid with a zero 4th channel so that the gather is one aligned
+// 16-byte load per tap (FAST loader) instead of twelve scalar ones, and the weight gradient is compacted back.
+__global__ void pad3to4_kernel(const float* __restrict__ x, f32x4* __restrict__ x4, long long npix) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = {x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f};
+    x4[i] = v;
+  }
+}
+__global__ void compact4to3_kernel(const float* __restrict__ dw4, float* __restrict__ dw, long long n3, float beta) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i / 3;
+    const int c = (int)(i - 3 * t);
+    dw[i] = (beta != 0.f ? beta * dw[i] : 0.f) + dw4[4 * t + c];
+  }
+}
+
 struct WgradPlan {
   int bc, k_tiles, c_tiles, nsplit, pix_per_split;
   size_t slab_bytes, bias_bytes;
@@ -714,6 +730,19 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   return MUNIT_OK;
 }
 
+bool cin3_padded_ok(const munit_conv_desc* d) {
+  return d->Cin == 3 && d->Cout % 4 == 0 && d->upsample == 0 && !getenv("MUNIT_DEBUG_NO_CIN3_PAD");
+}
+struct Cin3Plan {
+  WgradPlan pl;
+  size_t x4_bytes, dw4_bytes;
+};
+void plan_cin3(const munit_conv_desc* d, int Ho, int Wo, Cin3Plan* cp) {
+  plan_launch(d->B * Ho * Wo, d->KH * d->KW * 4, d->Cout, true, &cp->pl);
+  cp->x4_bytes = align_up((size_t)d->B * d->H * d->W * 4 * sizeof(float), 256);
+  cp->dw4_bytes = align_up((size_t)d->Cout * d->KH * d->KW * 4 * sizeof(float), 256);
+}
+
 bool subpixel_wgrad_ok(const munit_conv_desc* d) {
   return d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
          d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 4 == 0 && d->H >= 3 && d->W >= 3 &&
@@ -744,6 +773,11 @@ extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
     SubpixelPlan sp;
     plan_subpixel(d, &sp);
     return sp.dwc_bytes + sp.slab_bytes;
+  }
+  if (cin3_padded_ok(d)) {
+    Cin3Plan cp;
+    plan_cin3(d, Ho, Wo, &cp);
+    return cp.x4_bytes + cp.dw4_bytes + cp.pl.slab_bytes + cp.pl.bias_bytes;
   }
   WgradPlan pl;
   plan_launch(d->B * Ho * Wo, d->KH * d->KW * d->Cin, d->Cout, d->Cin % 4 == 0, &pl);
@@ -804,6 +838,27 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(upw_scatter_kernel, dim3(blocks), dim3(256), 0, st, dwc, dw, d->Cout, d->Cin);
     MUNIT_CHECK_LAUNCH("upw_scatter");
+    return MUNIT_OK;
+  }
+  if (cin3_padded_ok(d)) {
+    Cin3Plan cp;
+    plan_cin3(d, Ho, Wo, &cp);
+    float* x4 = reinterpret_cast<float*>(ws);
+    float* dw4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cp.x4_bytes);
+    void* slabs = reinterpret_cast<char*>(ws) + cp.x4_bytes + cp.dw4_bytes;
+    const long long npix = (long long)d->B * d->H * d->W;
+    hipLaunchKernelGGL(pad3to4_kernel, dim3((unsigned)std::min<long long>((npix + 255) / 256, 8192)), dim3(256), 0, st, x,
+                       reinterpret_cast<f32x4*>(x4), npix);
+    MUNIT_CHECK_LAUNCH("pad3to4");
+    WgradParams q = p;
+    q.x = x4; q.Cin = 4; q.Ktot = d->KH * d->KW * 4;
+    q.ct = 0;   // 4 channels per tap: not a multiple of the bf16 K granularity, stays fp32
+    rc = run_wgrad(q, cp.pl, true, dw4, db, 0.0f, beta, slabs, st);
+    if (rc) return rc;
+    const long long n3 = (long long)d->Cout * d->KH * d->KW * 3;
+    hipLaunchKernelGGL(compact4to3_kernel, dim3((unsigned)std::min<long long>((n3 + 255) / 256, 4096)), dim3(256), 0, st, dw4, dw,
+                       n3, beta);
+    MUNIT_CHECK_LAUNCH("compact4to3");
     return MUNIT_OK;
   }
   WgradPlan pl;

@@ -10,6 +10,7 @@ gradient storage) backward-weight accumulates straight into it (beta = 1) and au
 None; otherwise the gradient is returned the ordinary way (used by the op-level tests).
 """
 import ctypes
+import os
 from ctypes import byref, c_float, c_int, c_void_p
 
 import torch
@@ -79,8 +80,8 @@ def empty_nhwc(b, c, h, w, like):
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (stream-ordered reuse on the current stream)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream it is used on."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes * 1.25), 1 << 20)
@@ -179,6 +180,29 @@ def act_bwd_raw(act, slope, y, dy):
 # ------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------
+# Backward-weight runs on a side stream: it only feeds the optimizer, so it need not sit in the dy -> dx chain.
+# Launched before the layer's backward-data, it fills the CUs that the chain leaves idle at kernel heads and tails
+# (e.g. while the few blocks of a folded backward-data launch that hold 4-fold corner pixels finish).  All
+# backward-weight launches share the one side stream, so accumulations into the same flat gradient stay ordered.
+_SIDE = {}
+SIDE_STREAM_WGRAD = not os.environ.get("MUNIT_NO_SIDE_STREAM")
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
+
+
+def join_side_streams():
+    """Make the current stream wait for every backward-weight launched so far (call before the optimizer step)."""
+    for (_, index), st in _SIDE.items():
+        torch.cuda.current_stream(torch.device("cuda", index)).wait_stream(st)
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf):
@@ -201,14 +225,23 @@ class _Conv2d(Function):
         if act != "none":
             dy = act_bwd_raw(act, slope, y, dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if ctx.wbuf is not None:
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if want_w and ctx.wbuf is not None:
+            if SIDE_STREAM_WGRAD:
+                main, side = torch.cuda.current_stream(dy.device), _side_stream(dy.device)
+                side.wait_stream(main)          # dy, x and the zeroed gradient buffer are ready on main
+                with torch.cuda.stream(side):
+                    conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf,
+                                     beta=1.0, want_bias=False)
+                x.record_stream(side)
+                dy.record_stream(side)
+            else:
                 conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
                                  want_bias=False)
-            else:
-                dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample)
+        if want_w and ctx.wbuf is None:
+            dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 

@@ -388,6 +388,7 @@ class MUNIT_Trainer(nn.Module):
         self.loss_gen_total = ops.weighted_sum([t.detach() for _, t in pairs], [w for w, _ in pairs])
         live = [(w, t) for w, t in pairs if w != 0 and t.requires_grad]
         torch.autograd.backward([t for _, t in live], [self._const(w, dev) for w, _ in live])
+        ops.join_side_streams()          # backward-weight kernels run on a side stream
         self._all_reduce_mean(self.gen_opt.flat_g)
         self.gen_opt_step()
         self._log(comet_exp, ("loss_gen_adv_a", "loss_gen_adv_b", "loss_gen_recon_x_a", "loss_gen_recon_s_a",
@@ -421,6 +422,7 @@ class MUNIT_Trainer(nn.Module):
                                                [hp["gan_w"], hp["gan_w"]])
         w = self._const(hp["gan_w"], dev)
         torch.autograd.backward([self.loss_dis_a, self.loss_dis_b], [w, w])
+        ops.join_side_streams()
         self._all_reduce_mean(self.dis_opt.flat_g)
         self.dis_opt_step()
         self._log(comet_exp, ("loss_dis_b", "loss_dis_a"))

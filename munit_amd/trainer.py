@@ -154,6 +154,54 @@ class FusedExtraAdam(FusedAdam):
         self._has_copy = False
 
 
+class _Branches:
+    """The a / b halves of an update on two streams.  Every stage of gen_update / dis_update consists of two
+    independent halves (encode x_a | encode x_b, decode ... ), so running them on two streams lets the head and
+    tail of one kernel overlap the body of another and fills the small grids of the discriminators.  Autograd
+    replays each node on the stream it was recorded on, so the backward pass forks the same way.
+    `share` is the cross-over point: both streams wait for each other and the tensors named become usable (and
+    allocator-safe) on both.  MUNIT_NO_BRANCH_STREAMS=1 keeps everything on the caller's stream."""
+    _streams = {}
+
+    def __init__(self, dev):
+        self.enabled = torch.cuda.is_available() and not os.environ.get("MUNIT_NO_BRANCH_STREAMS")
+        if not self.enabled:
+            return
+        self.main = torch.cuda.current_stream(dev)
+        key = (dev.type, dev.index)
+        if key not in _Branches._streams:
+            _Branches._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self.s = _Branches._streams[key]
+        for st in self.s:
+            st.wait_stream(self.main)
+
+    def run(self, k, fn):
+        if not self.enabled:
+            return fn()
+        with torch.cuda.stream(self.s[k]):
+            return fn()
+
+    def share(self, *tensors):
+        if not self.enabled:
+            return
+        ea, eb = self.s[0].record_event(), self.s[1].record_event()
+        self.s[0].wait_event(eb)
+        self.s[1].wait_event(ea)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self.s[0])
+                t.record_stream(self.s[1])
+
+    def join(self, *tensors):
+        if not self.enabled:
+            return
+        for st in self.s:
+            self.main.wait_stream(st)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self.main)
+
+
 class MUNIT_Trainer(nn.Module):
     def __init__(self, hyperparameters):
         super(MUNIT_Trainer, self).__init__()
@@ -333,45 +381,52 @@ class MUNIT_Trainer(nn.Module):
         for p in d_params:  # D weight gradients made here would be discarded (trainer.py:1145)
             p.requires_grad_(False)
         try:
-            c_a, s_a_prime = self._enc(x_a, 1)
-            c_b, s_b_prime = self._enc(x_b, 2)
-            x_a_recon = self._dec(c_a, s_a_prime, 1)
-            x_b_recon = self._dec(c_b, s_b_prime, 2)
+            br = _Branches(dev)
+            br.share(x_a, x_b, mask_a, mask_b)
+            c_a, s_a_prime = br.run(0, lambda: self._enc(x_a, 1))
+            c_b, s_b_prime = br.run(1, lambda: self._enc(x_b, 2))
+            x_a_recon = br.run(0, lambda: self._dec(c_a, s_a_prime, 1))
+            x_b_recon = br.run(1, lambda: self._dec(c_b, s_b_prime, 2))
             if self.guided == 0:
                 s_a_use, s_b_use = s_a.to(dev), s_b.to(dev)
             elif self.guided == 1:
                 s_a_use, s_b_use = s_a_prime, s_b_prime
             else:
                 raise ValueError("self.guided unknown value: %r" % (self.guided,))
-            x_ba = self._dec(c_b, s_a_use, 1)
-            x_ab = self._dec(c_a, s_b_use, 2)
-            c_b_recon, s_a_recon = self._enc(x_ba, 1)
-            c_a_recon, s_b_recon = self._enc(x_ab, 2)
+            br.share(c_a, c_b, s_a_use, s_b_use)
+            x_ba = br.run(0, lambda: self._dec(c_b, s_a_use, 1))
+            x_ab = br.run(1, lambda: self._dec(c_a, s_b_use, 2))
+            c_b_recon, s_a_recon = br.run(0, lambda: self._enc(x_ba, 1))
+            c_a_recon, s_b_recon = br.run(1, lambda: self._enc(x_ab, 2))
+            br.share(c_a_recon, c_b_recon)
             cyc = hp["recon_x_cyc_w"] > 0
-            x_aba = self._dec(c_a_recon, s_a_prime, 1) if cyc else None
-            x_bab = self._dec(c_b_recon, s_b_prime, 2) if cyc else None
+            x_aba = br.run(0, lambda: self._dec(c_a_recon, s_a_prime, 1)) if cyc else None
+            x_bab = br.run(1, lambda: self._dec(c_b_recon, s_b_prime, 2)) if cyc else None
 
-            self.loss_gen_recon_x_a = self.recon_criterion(x_a_recon, x_a)
-            self.loss_gen_recon_x_b = self.recon_criterion(x_b_recon, x_b)
-            self.loss_gen_recon_s_a = self.recon_criterion(s_a_recon, s_a_use)
-            self.loss_gen_recon_s_b = self.recon_criterion(s_b_recon, s_b_use)
-            self.loss_gen_recon_c_a = self.recon_criterion(c_a_recon, c_a)
-            self.loss_gen_recon_c_b = self.recon_criterion(c_b_recon, c_b)
+            self.loss_gen_recon_x_a = br.run(0, lambda: self.recon_criterion(x_a_recon, x_a))
+            self.loss_gen_recon_x_b = br.run(1, lambda: self.recon_criterion(x_b_recon, x_b))
+            self.loss_gen_recon_s_a = br.run(0, lambda: self.recon_criterion(s_a_recon, s_a_use))
+            self.loss_gen_recon_s_b = br.run(1, lambda: self.recon_criterion(s_b_recon, s_b_use))
+            self.loss_gen_recon_c_a = br.run(1, lambda: self.recon_criterion(c_a_recon, c_a))
+            self.loss_gen_recon_c_b = br.run(0, lambda: self.recon_criterion(c_b_recon, c_b))
             self.loss_gen_recon_synth = 0
             if cyc:
                 if self.recon_mask:
                     if mask_a is None or mask_b is None:
                         raise ValueError("recon_mask == 1 needs mask_a and mask_b of shape (B,1,H,W)")
-                    self.loss_gen_cycrecon_x_a = self.recon_criterion_mask(x_aba, x_a, mask_a)
-                    self.loss_gen_cycrecon_x_b = self.recon_criterion_mask(x_bab, x_b, mask_b)
+                    self.loss_gen_cycrecon_x_a = br.run(0, lambda: self.recon_criterion_mask(x_aba, x_a, mask_a))
+                    self.loss_gen_cycrecon_x_b = br.run(1, lambda: self.recon_criterion_mask(x_bab, x_b, mask_b))
                 else:
-                    self.loss_gen_cycrecon_x_a = self.recon_criterion(x_aba, x_a)
-                    self.loss_gen_cycrecon_x_b = self.recon_criterion(x_bab, x_b)
+                    self.loss_gen_cycrecon_x_a = br.run(0, lambda: self.recon_criterion(x_aba, x_a))
+                    self.loss_gen_cycrecon_x_b = br.run(1, lambda: self.recon_criterion(x_bab, x_b))
             else:
                 self.loss_gen_cycrecon_x_a = 0
                 self.loss_gen_cycrecon_x_b = 0
-            self.loss_gen_adv_a = self.dis_a.calc_gen_loss(x_ba)
-            self.loss_gen_adv_b = self.dis_b.calc_gen_loss(x_ab)
+            self.loss_gen_adv_a = br.run(0, lambda: self.dis_a.calc_gen_loss(x_ba))
+            self.loss_gen_adv_b = br.run(1, lambda: self.dis_b.calc_gen_loss(x_ab))
+            br.join(self.loss_gen_recon_x_a, self.loss_gen_recon_x_b, self.loss_gen_recon_s_a, self.loss_gen_recon_s_b,
+                    self.loss_gen_recon_c_a, self.loss_gen_recon_c_b, self.loss_gen_cycrecon_x_a,
+                    self.loss_gen_cycrecon_x_b, self.loss_gen_adv_a, self.loss_gen_adv_b)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -388,6 +443,7 @@ class MUNIT_Trainer(nn.Module):
         self.loss_gen_total = ops.weighted_sum([t.detach() for _, t in pairs], [w for w, _ in pairs])
         live = [(w, t) for w, t in pairs if w != 0 and t.requires_grad]
         torch.autograd.backward([t for _, t in live], [self._const(w, dev) for w, _ in live])
+        br.join()                        # the backward pass ran on the branch streams its nodes were recorded on
         ops.join_side_streams()          # backward-weight kernels run on a side stream
         self._all_reduce_mean(self.gen_opt.flat_g)
         self.gen_opt_step()
@@ -405,23 +461,28 @@ class MUNIT_Trainer(nn.Module):
         s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
         dev = x_a.device
         x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
+        br = _Branches(dev)
+        br.share(x_a, x_b)
         with torch.no_grad():  # the generator graph would never be back-propagated here
-            c_a, s_a_prime = self._enc(x_a, 1)
-            c_b, s_b_prime = self._enc(x_b, 2)
+            c_a, s_a_prime = br.run(0, lambda: self._enc(x_a, 1))
+            c_b, s_b_prime = br.run(1, lambda: self._enc(x_b, 2))
             if self.guided == 0:
-                x_ba = self._dec(c_b, s_a.to(dev), 1)
-                x_ab = self._dec(c_a, s_b.to(dev), 2)
+                s_a_use, s_b_use = s_a.to(dev), s_b.to(dev)
             elif self.guided == 1:
-                x_ba = self._dec(c_b, s_a_prime, 1)
-                x_ab = self._dec(c_a, s_b_prime, 2)
+                s_a_use, s_b_use = s_a_prime, s_b_prime
             else:
                 raise ValueError("self.guided unknown value: %r" % (self.guided,))
-        self.loss_dis_a = self.dis_a.calc_dis_loss(x_ba.detach(), x_a)
-        self.loss_dis_b = self.dis_b.calc_dis_loss(x_ab.detach(), x_b)
+            br.share(c_a, c_b, s_a_use, s_b_use)
+            x_ba = br.run(0, lambda: self._dec(c_b, s_a_use, 1))
+            x_ab = br.run(1, lambda: self._dec(c_a, s_b_use, 2))
+        self.loss_dis_a = br.run(0, lambda: self.dis_a.calc_dis_loss(x_ba.detach(), x_a))
+        self.loss_dis_b = br.run(1, lambda: self.dis_b.calc_dis_loss(x_ab.detach(), x_b))
+        br.join(self.loss_dis_a, self.loss_dis_b)
         self.loss_dis_total = ops.weighted_sum([self.loss_dis_a.detach(), self.loss_dis_b.detach()],
                                                [hp["gan_w"], hp["gan_w"]])
         w = self._const(hp["gan_w"], dev)
         torch.autograd.backward([self.loss_dis_a, self.loss_dis_b], [w, w])
+        br.join()
         ops.join_side_streams()
         self._all_reduce_mean(self.dis_opt.flat_g)
         self.dis_opt_step()

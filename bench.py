@@ -187,11 +187,19 @@ def main():
 
     if rank == 0 and not args.no_roofline and args.precision == "f32":
         step_flop = GFLOP_PER_PAIR_256 * 1e9 * (args.size / 256.0) ** 2 * args.batch
+        # single-kernel timing: the instrumented steps run on one stream (in the timed region other kernels share
+        # the chip with every launch, which stretches each launch's own duration while shortening the step)
+        from munit_amd import trainer as trainer_mod
+        saved = (ops.SIDE_STREAM_WGRAD, trainer_mod.BRANCH_STREAMS)
+        ops.SIDE_STREAM_WGRAD = trainer_mod.BRANCH_STREAMS = False
+        step()
+        torch.cuda.synchronize()
         ops.PROFILE = []
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
+        ops.SIDE_STREAM_WGRAD, trainer_mod.BRANCH_STREAMS = saved
         sel = [(fl, e0.elapsed_time(e1)) for (tag, fl, e0, e1) in recs if tag == "conv_igemm_kernel<128,true,fwd>"]
         if sel:
             tot_fl = sum(f for f, _ in sel)
@@ -205,7 +213,8 @@ def main():
                 "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                 "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),
                 "method": "HIP events around every launch of the kernel in 2 extra instrumented steps after "
-                          "the timed region; algorithmic FLOPs = 2*B*Ho*Wo*Cout*KH*KW*Cin per launch",
+                          "the timed region, run on a single stream (the timed region overlaps kernels on 3 streams, "
+                          "see step_frac); algorithmic FLOPs = 2*B*Ho*Wo*Cout*KH*KW*Cin per launch",
                 "step_achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
                 "step_frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "step_algorithmic_tflop": round(step_flop / 1e12, 3),

@@ -154,6 +154,9 @@ class FusedExtraAdam(FusedAdam):
         self._has_copy = False
 
 
+BRANCH_STREAMS = not os.environ.get("MUNIT_NO_BRANCH_STREAMS")   # bench.py clears it while it times single kernels
+
+
 class _Branches:
     """The a / b halves of an update on two streams.  Every stage of gen_update / dis_update consists of two
     independent halves (encode x_a | encode x_b, decode ... ), so running them on two streams lets the head and
@@ -164,7 +167,7 @@ class _Branches:
     _streams = {}
 
     def __init__(self, dev):
-        self.enabled = torch.cuda.is_available() and not os.environ.get("MUNIT_NO_BRANCH_STREAMS")
+        self.enabled = torch.cuda.is_available() and BRANCH_STREAMS
         if not self.enabled:
             return
         self.main = torch.cuda.current_stream(dev)

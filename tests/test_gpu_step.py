@@ -189,3 +189,44 @@ def test_hd_config_shapes_run():
     for k in ("loss_gen_total", "loss_dis_total"):
         v = float(getattr(tr, k))
         assert v == v and abs(v) < 1e4
+
+
+def test_multi_stream_step_is_bitwise_the_single_stream_step():
+    """The three-stream schedule (a/b branch streams + backward-weight side stream) must not change a single bit:
+    every kernel sees the same inputs and the flat gradients are accumulated in the same order.  A missing
+    cross-stream dependency shows up here as a mismatch (or as run-to-run noise)."""
+    import bench
+    from munit_amd import ops
+    from munit_amd import trainer as T
+    dev = torch.device("cuda:0")
+    size, batch = 128, 2
+    x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(batch, size))
+
+    def run(streams):
+        saved = (ops.SIDE_STREAM_WGRAD, T.BRANCH_STREAMS)
+        ops.SIDE_STREAM_WGRAD = T.BRANCH_STREAMS = streams
+        try:
+            hp = bench.bench_hp(size, batch)
+            torch.manual_seed(1234)
+            tr = T.MUNIT_Trainer(hp)
+            tr.to(dev)
+            torch.manual_seed(3)
+            for it in range(3):
+                tr.iterations = it
+                tr.update_learning_rate()
+                tr.dis_update(x_a, x_b, hp)
+                tr.gen_update(x_a, x_b, hp, m_a, m_b)
+            torch.cuda.synchronize()
+            sd = {("gen." + k): v.detach().clone() for k, v in tr.gen.state_dict().items()}
+            sd.update({("dis_a." + k): v.detach().clone() for k, v in tr.dis_a.state_dict().items()})
+            sd.update({("dis_b." + k): v.detach().clone() for k, v in tr.dis_b.state_dict().items()})
+            return sd, float(tr.loss_gen_total.detach()), float(tr.loss_dis_total.detach())
+        finally:
+            ops.SIDE_STREAM_WGRAD, T.BRANCH_STREAMS = saved
+
+    ref, lg, ld = run(False)
+    for _ in range(3):                       # repeated: a race is not guaranteed to bite on the first try
+        got, lg2, ld2 = run(True)
+        assert (lg2, ld2) == (lg, ld)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), k

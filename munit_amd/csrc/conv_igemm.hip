@@ -136,7 +136,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // barriers per K-tile) to keep two blocks per CU.
 template <int BN, bool ALIGNED, int ROLE, int CT = 0>
 __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
-  constexpr bool BF16 = CT != 0;
+  // CT == 3: fp32 MFMA as CT == 0, but the tiles travel global -> LDS directly (global_load_lds_dwordx4, no VGPR
+  // staging, no ds_write): forward convs whose every tap is a valid pixel (reflect padding or no padding), since
+  // the DMA path cannot substitute zeros.  Tiles are unpadded [row][32] floats (each wave instruction fills 8 rows
+  // = 1 KiB); bank conflicts are avoided by a swizzle instead: the lane that lands at 16-byte position p of row r
+  // fetches global chunk p ^ ((r >> 1) & 7), and the fragment reads undo it.
+  constexpr bool BF16 = CT == 1 || CT == 2;
+  constexpr bool DMA = CT == 3;
+  static_assert(!DMA || (ROLE == 0 && ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned forward variant only");
   constexpr int NPL = CT == 2 ? 3 : 1;     // bf16 planes per operand
   static_assert(!BF16 || ALIGNED, "bf16 operands need Cin % 32 == 0");
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
@@ -362,6 +369,34 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
     }
   };
 
+  const int dma_col = ((c4 ^ ((r0 >> 1) & 7)) * 4);   // global chunk (floats) this lane fetches; RSTEP % 16 == 0
+  auto dma_tile = [&](int kt, int buf) {
+    if constexpr (DMA) {
+      if (c0 == 0 || kt == kt_begin) tap_setup();
+      const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const float* g = xg + (long long)(aoff[i] >= 0 ? aoff[i] : 0) + c0 + dma_col;
+        float* l = smem + buf * (BM * 32) + (wrow + RSTEP * i) * 32;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        const int n = min(n0 + r0 + RSTEP * i, p.Cout - 1);
+        const float* g = wg + (long long)n * p.w_row + kt * BK + dma_col;
+        float* l = smem + 2 * BM * 32 + buf * (BN * 32) + (wrow + RSTEP * i) * 32;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      }
+      c0 += BK;
+      if (c0 >= p.Cin) {
+        c0 = 0;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
+    }
+  };
+
   // bf16 tiles: [row][32] bf16 = 64-byte rows without padding; the 16-byte chunk c of a row lives at
   // position c ^ F[(row>>2)&3], F = {0,2,3,1}, which makes the fragment ds_read_b128 conflict-free
   // (every 16-lane service group then touches 16 distinct (row&3, position) pairs = all 64 banks).
@@ -450,6 +485,26 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
       }
       return;
     }
+    if constexpr (DMA) {
+      const float* Ac = smem + buf * (BM * 32);
+      const float* Bc = smem + 2 * BM * 32 + buf * (BN * 32);
+      const int pos = ((kg * 4 + (lane >> 4)) ^ ((frag_row >> 1) & 7)) * 4;
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        b[nt] = *reinterpret_cast<const f32x4*>(&Bc[(wn * WN + nt * 16 + frag_row) * 32 + pos]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16 + frag_row) * 32 + pos]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+      return;
+    }
     const float* Ac = As + buf * (BM * LDS_LD);
     const float* Bc = Bs + buf * (BN * LDS_LD);
     f32x4 a[MT], b[NT];
@@ -480,7 +535,19 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   // passed the barrier that ended tile t-1 and nobody reads that buffer before the next barrier -- and the
   // loads of tile t+2 are issued into the freed registers.  One barrier per K-tile.
   const int nk = kt_end - kt_begin;
-  if constexpr (CT == 2) {
+  if constexpr (DMA) {
+    if (nk > 0) dma_tile(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) dma_tile(kt_begin + kt + 1, cur ^ 1);   // every wave finished reading that buffer before the last barrier
+      compute_half(cur, 0);
+      compute_half(cur, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else if constexpr (CT == 2) {
     // three planes, one LDS buffer: barrier, split the registers (tile kt) into the planes, issue the loads of
     // tile kt+1, barrier, multiply.  The other resident block covers the store phase.
     if (nk > 0) load_tile(kt_begin);
@@ -789,6 +856,10 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
     }
+  } else if (ROLE == 0 && aligned && p.ct == 0 && (p.reflect || p.pad == 0) && NWAVES == 8 && !getenv("MUNIT_DEBUG_NO_DMA")) {
+    // every tap of every output pixel is a real pixel: tiles can go global -> LDS directly
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 0, 3>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 0, 3>), grid, block, 0, st, q);
   } else if (bn == 64) {
     if (aligned && p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 2>), grid, block, 0, st, q);
     else if (aligned && p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 1>), grid, block, 0, st, q);

@@ -128,6 +128,10 @@ __device__ inline int cand_at(uint2 v, int a) {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// 128 bytes of zeros in device memory: the direct-to-LDS loads cannot substitute a value, so a tap that falls into
+// zero padding (or a row past M) is pointed here instead
+__device__ const float munit_zero_page[32] = {0.f};
+
 // CT (compute type): 0 = fp32 MFMA; 1 = bf16 operands; 2 = "f32x3": every fp32 operand is split exactly into
 // three bf16 planes a = a0 + a1 + a2 (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)) and the six
 // products a_i * b_j with i + j <= 2 are accumulated in fp32.  The dropped terms are <= 2^-24 |a||b|; measured
@@ -137,13 +141,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int BN, bool ALIGNED, int ROLE, int CT = 0>
 __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
   // CT == 3: fp32 MFMA as CT == 0, but the tiles travel global -> LDS directly (global_load_lds_dwordx4, no VGPR
-  // staging, no ds_write): forward convs whose every tap is a valid pixel (reflect padding or no padding), since
-  // the DMA path cannot substitute zeros.  Tiles are unpadded [row][32] floats (each wave instruction fills 8 rows
+  // staging, no ds_write); taps in zero padding read munit_zero_page.  Not for ROLE 2, which adds gathers.  Tiles are unpadded [row][32] floats (each wave instruction fills 8 rows
   // = 1 KiB); bank conflicts are avoided by a swizzle instead: the lane that lands at 16-byte position p of row r
   // fetches global chunk p ^ ((r >> 1) & 7), and the fragment reads undo it.
   constexpr bool BF16 = CT == 1 || CT == 2;
   constexpr bool DMA = CT == 3;
-  static_assert(!DMA || (ROLE == 0 && ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned forward variant only");
+  static_assert(!DMA || (ROLE != 2 && ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned single-gather variants only");
   constexpr int NPL = CT == 2 ? 3 : 1;     // bf16 planes per operand
   static_assert(!BF16 || ALIGNED, "bf16 operands need Cin % 32 == 0");
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
       const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        const float* g = xg + (long long)(aoff[i] >= 0 ? aoff[i] : 0) + c0 + dma_col;
+        const float* g = aoff[i] >= 0 ? xg + (long long)aoff[i] + c0 + dma_col : munit_zero_page + dma_col;
         float* l = smem + buf * (BM * 32) + (wrow + RSTEP * i) * 32;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -856,10 +859,10 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
     }
-  } else if (ROLE == 0 && aligned && p.ct == 0 && (p.reflect || p.pad == 0) && NWAVES == 8 && !getenv("MUNIT_DEBUG_NO_DMA")) {
-    // every tap of every output pixel is a real pixel: tiles can go global -> LDS directly
-    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 0, 3>), grid, block, 0, st, q);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 0, 3>), grid, block, 0, st, q);
+  } else if (aligned && p.ct == 0 && NWAVES == 8 && !getenv("MUNIT_DEBUG_NO_DMA")) {
+    // single-gather fp32 variants: tiles go global -> LDS directly
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 3>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 3>), grid, block, 0, st, q);
   } else if (bn == 64) {
     if (aligned && p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 2>), grid, block, 0, st, q);
     else if (aligned && p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 1>), grid, block, 0, st, q);

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
       const int cur = kt & 1;
       compute_half(cur, 0);
       if (kt + 1 < nk) {
+        // ABL_*: timing-only ablation builds (`make alt ALTFLAGS=-DABL_NOGLOBAL`, results are wrong), DESIGN.md section 3.5
 #ifndef ABL_NOLDSW
         store_tile(cur ^ 1);
 #endif
@@ -1115,7 +1116,6 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     p.y_sb = (long long)d->H * d->W * d->Cin;
     p.M = d->B * d->H * d->W;
     p.act = MUNIT_ACT_NONE; p.slope = 0.f;
-  p.ct = d->compute;
     p.ct = d->compute;
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;

@@ -835,7 +835,7 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
   q.n_tiles = cdiv(p.Cout, bn);
   const int m_tiles = cdiv(p.M, BM);
   q.ksplit = 1;
-  if (slab != nullptr && ROLE != 2) {
+  if (slab != nullptr) {
     const int ks = pick_ksplit(p.M, p.Cout, p.Ktot, phases);
     if (ks > 1 && slab_bytes >= splitk_bytes(p.M, p.Cout, p.Ktot, phases)) {
       const int nk = cdiv(p.Ktot, BK);
@@ -996,11 +996,33 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
 }
 
 namespace {
+// S[b][u][v][c] = dy[u][v] + dy[u+1][v] + dy[u][v+1] + dy[u+1][v+1] (terms past the last row / column are zero): the four
+// up-sampled positions 2i+a, 2j+b of a source pixel are a 2x2 block of dy for every tap, so the backward-data of an
+// up-sampling conv over the interior becomes a single-gather stride-2 correlation over S.
+__global__ void box2x2_kernel(const f32x4* __restrict__ dy, f32x4* __restrict__ s, int B, int H, int W, int C4) {
+  const long long total = (long long)B * H * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long r = i / C4;
+    const int v = (int)(r % W); r /= W;
+    const int u = (int)(r % H);
+    f32x4 a = dy[i];
+    if (v + 1 < W) a += dy[i + C4];
+    if (u + 1 < H) {
+      a += dy[i + (long long)W * C4];
+      if (v + 1 < W) a += dy[i + (long long)W * C4 + C4];
+    }
+    s[i] = a;
+    (void)c;
+  }
+}
+
 struct DgradPlan {
   int Ho, Wo, ps, TH, TW, Hq, Wq;
   bool direct;  // write dx directly (no pad / upsample / add): 1x1 convs, linear layers
   bool folded;  // stride-1, Cout % 32 == 0: pad/upsample adjoint folded into the gather (ROLE 2)
   bool small;   // 3 input channels, 7x7: padded-domain correlation on the thread-per-pixel VALU kernel
+  bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
   size_t wt_bytes, g_bytes, sk_bytes;
 };
 // number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
@@ -1046,9 +1068,16 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     if (pl->small) pl->folded = false;
     if (getenv("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
   }
+  pl->boxsum = pl->folded && d->upsample == 1 && d->KH == 5 && d->pad == 2 && reflect && d->Cout % 32 == 0 &&
+               d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !getenv("MUNIT_DEBUG_NO_BOXSUM");
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
+  if (pl->boxsum) pl->g_bytes = align_up((size_t)d->B * pl->Ho * pl->Wo * d->Cout * sizeof(float), 256);  // S
+  if (pl->boxsum) {
+    pl->sk_bytes = splitk_bytes(d->B * (4 * d->W + 4 * (d->H - 4)), d->Cin, d->KH * d->KW * d->Cout, 1);
+    return MUNIT_OK;
+  }
   pl->sk_bytes = (pl->folded || pl->small) ? 0
                  : splitk_bytes(d->B * (pl->Ho + pl->TH - 1) * (pl->Wo + pl->TW - 1), d->Cin,
                                 pl->TH * pl->TW * d->Cout, pl->ps * pl->ps);
@@ -1120,7 +1149,29 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
-    rc = launch_igemm<2>(p, 1, st);
+    if (pl.boxsum) {
+      // interior source pixels 2..H-3 x 2..W-3: dx[i][j] = sum_taps wt[t][r] . S[2i-2+t][2j-2+r] -- one gather per element
+      {
+        const long long total = (long long)d->B * pl.Ho * pl.Wo * (d->Cout / 4);
+        hipLaunchKernelGGL(box2x2_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, st,
+                           reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(g), d->B, pl.Ho, pl.Wo, d->Cout / 4);
+        MUNIT_CHECK_LAUNCH("box2x2");
+      }
+      IgemmParams q = p;
+      q.x = g;
+      q.y = dx + ((long long)2 * d->W + 2) * d->Cin;
+      q.Ho = d->H - 4; q.Wo = d->W - 4;
+      q.stride = 2; q.pad = -2;
+      q.M = d->B * q.Ho * q.Wo;
+      rc = launch_igemm<0>(q, 1, st);
+      if (rc) return rc;
+      // the 2-pixel frame keeps the general folded gather (reflections add further positions there), split over K
+      p.frame = 1;
+      p.M = d->B * (4 * d->W + 4 * (d->H - 4));
+      rc = launch_igemm<2>(p, 1, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
+    } else {
+      rc = launch_igemm<2>(p, 1, st);
+    }
     if (rc) return rc;
     if (add != nullptr) {
       long long n = (long long)d->B * d->H * d->W * d->Cin;

@@ -32,6 +32,8 @@ CONV_CASES = [
     (256, 256, 3, 1, 1, "reflect", 0, "none", 2, 8, 8),     # resblock conv
     (256, 128, 5, 1, 2, "reflect", 1, "none", 2, 6, 8),     # upsample x2 + 5x5
     (128, 64, 5, 1, 2, "reflect", 1, "none", 1, 9, 7),
+    (256, 128, 5, 1, 2, "reflect", 1, "relu", 2, 12, 10),   # large enough for the box-sum backward-data (H, W >= 8)
+    (128, 64, 5, 1, 2, "reflect", 1, "none", 1, 8, 19),
     (64, 3, 7, 1, 3, "reflect", 0, "tanh", 2, 16, 12),      # image head (N=3)
     (3, 64, 4, 2, 1, "reflect", 0, "lrelu", 2, 16, 16),     # D first layer (K=48)
     (256, 512, 4, 2, 1, "reflect", 0, "lrelu", 2, 4, 4),    # D last layer

@@ -207,3 +207,23 @@ def test_data_parallel_exchange_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_compute_mode_plumbing_without_gpu():
+    """munit_conv_desc.compute / ops.set_compute: names, values and validation (no kernel is launched)."""
+    import ctypes
+    from munit_amd import _lib, ops
+    assert _lib.COMPUTE == {"f32": 0, "bf16": 1, "f32x3": 2}
+    fields = [f[0] for f in _lib.ConvDesc._fields_]
+    assert fields[-2:] == ["slope", "compute"] and ctypes.sizeof(_lib.ConvDesc) == 14 * 4
+    assert ops.get_compute() == "f32"
+    ops.set_compute("f32x3")
+    assert ops.get_compute() == "f32x3"
+    ops.set_compute("f32")
+    with pytest.raises(ValueError):
+        ops.set_compute("fp16")
+    lib = _lib.load()
+    d = _lib.ConvDesc(1, 8, 8, 32, 32, 3, 3, 1, 1, 1, 0, 0, 0.0, 7)        # unknown compute mode
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    assert lib.munit_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) != 0
+    assert b"compute" in lib.munit_last_error()

@@ -61,14 +61,14 @@ def pmc_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md; bench.py cannot collect PMC itself).
     Returns (bytes, source) or (None, None)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_hbm_mfma.txt")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_pmc_hbm_mfma.txt")
     try:
         for line in open(path):
-            if line.startswith("conv_igemm_kernel<128, true, 0>") and "blocks=   512" in line:
+            if line.startswith("conv_igemm_kernel<128, true, 0, 3>") and "blocks=   512" in line:
                 f = line.split()
                 fetch = float(f[f.index("fetch") + 1])
                 write = float(f[f.index("write") + 1])
-                return (fetch + write) * 1e6, "profiles/r01_c_pmc_hbm_mfma.txt (512-block launches: %.0f MB read + %.0f MB written)" % (fetch, write)
+                return (fetch + write) * 1e6, "profiles/r01_h_pmc_hbm_mfma.txt (512-block launches: %.0f MB read + %.0f MB written)" % (fetch, write)
     except (OSError, ValueError):
         pass
     return None, None

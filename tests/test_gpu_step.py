@@ -37,7 +37,7 @@ def test_modules_match_golden_forward(golden, gs):
         assert nerr(o, torch.from_numpy(arrays[key + "_dis%d" % i])) <= 1e-4
 
 
-@pytest.mark.parametrize("gs,iters", [(1, 3), (0, 1)])
+@pytest.mark.parametrize("gs,iters", [(1, 2), (0, 1)])   # the iterations run the fp64 oracle on the host: ~30 s each
 def test_step_matches_oracle(gs, iters):
     rep = run_step_parity(size=64, batch=2, gen_state=gs, iters=iters, device="cuda:0")
     print(rep)

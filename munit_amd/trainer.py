@@ -507,6 +507,24 @@ class MUNIT_Trainer(nn.Module):
                 self.gen_scheduler.step()
 
     # ---- sampling (trainer.py:773-928, core outputs only) -------------------------------
+    def sample_fid(self, x_a, x_b):
+        """trainer.py:1087-1131: per-sample cross-domain translation a -> b with the style encoded from x_b
+        (guided == 1); returns x_ab1 (trainer.py:1126-1131)."""
+        ops.set_compute(self.precision)
+        self.eval()
+        x_ab1 = []
+        with torch.no_grad():
+            for i in range(x_a.size(0)):
+                c_a, _ = self._enc(x_a[i:i + 1], 1)
+                _, s_b_fake = self._enc(x_b[i:i + 1], 2)
+                if self.guided == 1:
+                    x_ab1.append(self._dec(c_a, s_b_fake, 2))
+                else:
+                    print("self.guided unknown value:", self.guided)
+        x_ab1 = torch.cat(x_ab1)
+        self.train()
+        return x_ab1
+
     def sample(self, x_a, x_b):
         ops.set_compute(self.precision)
         self.eval()

@@ -171,3 +171,47 @@ def test_train_loop_example_runs(tmp_path):
         v = float(getattr(tr, name))
         assert v == v and v > 0
     assert sorted(os.listdir(tmp_path / "ckpt"))[:2] == ["dis_00000003.pt", "gen_00000003.pt"]
+
+
+def test_translate_folder_example_and_sample_fid(tmp_path):
+    """examples/translate_folder.py (the reference's test.py harness) end to end, and MUNIT_Trainer.sample_fid."""
+    import yaml
+    from PIL import Image
+    import bench
+    from munit_amd.trainer import MUNIT_Trainer
+    rng = np.random.RandomState(4)
+    (tmp_path / "content").mkdir()
+    for k in range(2):
+        Image.fromarray(_img(rng, 70 + 8 * k, 90, "noise")).save(tmp_path / "content" / ("c%d.png" % k))
+    Image.fromarray(_img(rng, 100, 80, "ramp")).save(tmp_path / "style.png")
+    hp = bench.bench_hp(64, 1)
+    hp.update(new_size=64)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump(hp))
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(hp)
+    tr.to(torch.device("cuda:0"))
+    (tmp_path / "ckpt").mkdir()
+    tr.save(str(tmp_path / "ckpt"), 0)
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import translate_folder
+    outs = translate_folder.main(["--config", str(cfg), "--checkpoint", str(tmp_path / "ckpt" / "gen_00000001.pt"),
+                                  "--input-folder", str(tmp_path / "content"), "--style", str(tmp_path / "style.png"),
+                                  "--output-folder", str(tmp_path / "out"), "--save-input"])
+    assert [os.path.basename(o) for o in outs] == ["output000.jpg", "output001.jpg"]
+    im = Image.open(outs[0])
+    rs_w = int(64 * 90 / 70)                                          # Resize(64): shorter side 64, aspect kept -> 82
+    down = lambda n: (n + 2 - 4) // 2 + 1                             # the two 4x4 stride-2 convs, then two x2 up-samplings
+    assert im.size == (4 * down(down(rs_w)), 64)
+    assert sorted(os.listdir(tmp_path / "out")) == ["input000.jpg", "input001.jpg", "output000.jpg", "output001.jpg"]
+    # sample_fid = decode(content(x_a), style(x_b)) per sample
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).mul(2).sub(1).to("cuda:0")
+    y = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(2)).mul(2).sub(1).to("cuda:0")
+    got = tr.sample_fid(x, y)
+    with torch.no_grad():
+        tr.eval()
+        c, _ = tr.gen.encode(x[1:2], 1)
+        _, s = tr.gen.encode(y[1:2], 2)
+        want = tr.gen.decode(c, s, 2)
+        tr.train()
+    assert got.shape == (2, 3, 64, 64) and torch.equal(got[1:2], want)

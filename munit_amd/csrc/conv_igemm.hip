@@ -139,7 +139,7 @@ __device__ const float munit_zero_page[32] = {0.f};
 // K = 2304).  Six bf16 MFMAs cost 6/16 of one fp32 MFMA step.  Three planes are single-buffered in LDS (two
 // barriers per K-tile) to keep two blocks per CU.
 template <int BN, bool ALIGNED, int ROLE, int CT = 0>
-__global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4) : 2) void conv_igemm_kernel(IgemmParams p) {
   // CT == 3: fp32 MFMA as CT == 0, but the tiles travel global -> LDS directly (global_load_lds_dwordx4, no VGPR
   // staging, no ds_write); taps in zero padding read munit_zero_page.  Not for ROLE 2, which adds gathers.  Tiles are unpadded [row][32] floats (each wave instruction fills 8 rows
   // = 1 KiB); bank conflicts are avoided by a swizzle instead: the lane that lands at 16-byte position p of row r
@@ -165,7 +165,9 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? 4 : 2) void conv_igemm_kernel(I
   // double-buffered A/B tiles: one barrier per K-tile (72 KiB at BN=128: two blocks per CU)
   constexpr int CLD = BN + 4;   // row stride of the epilogue's C staging tile (floats): conflict-free b32 writes
   static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "C staging tile must fit in the operand buffers");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+  // direct-to-LDS variant: unpadded tiles; with BN = 64 that is 48 KiB -> three blocks (6 waves per SIMD) per CU
+  constexpr int SMEM_FLOATS = CT == 3 ? (2 * (BM + BN) * 32 > BM * CLD ? 2 * (BM + BN) * 32 : BM * CLD) : 2 * (BM + BN) * LDS_LD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* const As = smem;
   float* const Bs = smem + 2 * BM * LDS_LD;
 

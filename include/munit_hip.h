@@ -90,6 +90,15 @@ int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy
                        float* db, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* dx = dy * act'(y) for the fused activations (y = post-activation output). n elements. */
+/* nn.Linear of LinearBlock (scripts/networks.py:712, 743-749) under its own name: y[B][N] = act(x[B][K] w[N][K]^T + bias),
+ * i.e. the 1x1 convolution on a [B][1][1][K] image (same kernels).  bwd: dx (or NULL), dw = beta*dw + dy^T x and
+ * db likewise (or NULL); dy is the gradient at the PRE-activation output (apply munit_act_bwd first). */
+size_t munit_linear_workspace_bytes(int B, int K, int N);
+int munit_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
+                     float slope, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int K,
+                     int N, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
+
 int munit_act_bwd(int act, float slope, const float* y, const float* dy, float* dx, size_t n,
                   munit_stream_t stream);
 

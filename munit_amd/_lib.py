@@ -45,6 +45,9 @@ SIGNATURES = {
     "munit_conv2d_dgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, c_size_t, _P]),
     "munit_conv2d_wgrad_workspace_bytes": (c_size_t, [_DESC]),
     "munit_conv2d_wgrad": (c_int, [_DESC, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "munit_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "munit_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    "munit_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "munit_act_bwd": (c_int, [c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "munit_instnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "munit_instnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int,

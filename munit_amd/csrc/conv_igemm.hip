@@ -1222,3 +1222,40 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
   }
   return MUNIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.Linear (LinearBlock, scripts/networks.py:712, 743-749) as named entry points: y[B][N] = act(x[B][K] w[N][K]^T + b).
+// They are the 1x1 convolution on a [B][1][1][K] image -- same kernels, same workspaces.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+munit_conv_desc linear_desc(int B, int K, int N, int act, float slope, int compute) {
+  munit_conv_desc d{};
+  d.B = B; d.H = 1; d.W = 1; d.Cin = K; d.Cout = N; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+  d.pad_mode = MUNIT_PAD_ZERO; d.upsample = 0; d.act = act; d.slope = slope; d.compute = compute;
+  return d;
+}
+}  // namespace
+
+extern "C" size_t munit_linear_workspace_bytes(int B, int K, int N) {
+  const munit_conv_desc d = linear_desc(B, K, N, MUNIT_ACT_NONE, 0.f, MUNIT_COMPUTE_F32);
+  return std::max(std::max(munit_conv2d_fwd_workspace_bytes(&d), munit_conv2d_dgrad_workspace_bytes(&d)),
+                  munit_conv2d_wgrad_workspace_bytes(&d));
+}
+
+extern "C" int munit_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, int act,
+                                float slope, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  const munit_conv_desc d = linear_desc(B, K, N, act, slope, MUNIT_COMPUTE_F32);
+  return munit_conv2d_fwd(&d, x, w, bias, y, ws, ws_bytes, stream);
+}
+
+extern "C" int munit_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B,
+                                int K, int N, float beta, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  const munit_conv_desc d = linear_desc(B, K, N, MUNIT_ACT_NONE, 0.f, MUNIT_COMPUTE_F32);
+  if (dx != nullptr) {
+    const int rc = munit_conv2d_dgrad(&d, dy, w, nullptr, dx, ws, ws_bytes, stream);
+    if (rc) return rc;
+  }
+  if (dw != nullptr) return munit_conv2d_wgrad(&d, x, dy, dw, db, beta, ws, ws_bytes, stream);
+  return MUNIT_OK;
+}
+

@@ -278,3 +278,31 @@ def test_cpu_tensor_is_refused():
     from munit_amd import ops
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, "reflect")
+
+
+def test_linear_entry_points():
+    """munit_linear_fwd / munit_linear_bwd (the named C entry points of nn.Linear) straight through ctypes."""
+    import ctypes
+    from munit_amd import _lib
+    lib = _lib.load()
+    B, K, N = 5, 256, 4096
+    x, w, b, dy = rnd((B, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1), rnd((B, N), 4)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.relu(xr @ wr.t() + br)
+    yr.backward(dy)
+    d = dev()
+    xd, wd, bd = (t.float().to(d).contiguous() for t in (x, w, b))
+    y = torch.empty(B, N, device=d)
+    nws = lib.munit_linear_workspace_bytes(B, K, N)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=d)
+    vp = ctypes.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.munit_linear_fwd(vp(xd.data_ptr()), vp(wd.data_ptr()), vp(bd.data_ptr()), vp(y.data_ptr()), B, K, N,
+                                    _lib.ACT["relu"], ctypes.c_float(0.2), vp(ws.data_ptr()), ctypes.c_size_t(nws), st), "linear_fwd")
+    assert nerr(y, yr) <= FWD_TOL
+    g = (dy * (yr > 0)).float().to(d).contiguous()      # gradient at the pre-activation output
+    dx, dw, db = torch.empty_like(xd), torch.empty_like(wd), torch.empty_like(bd)
+    _lib.check(lib.munit_linear_bwd(vp(xd.data_ptr()), vp(wd.data_ptr()), vp(g.data_ptr()), vp(dx.data_ptr()),
+                                    vp(dw.data_ptr()), vp(db.data_ptr()), B, K, N, ctypes.c_float(0.0), vp(ws.data_ptr()),
+                                    ctypes.c_size_t(nws), st), "linear_bwd")
+    assert nerr(dx, xr.grad) <= BWD_TOL and nerr(dw, wr.grad) <= BWD_TOL and nerr(db, br.grad) <= BWD_TOL

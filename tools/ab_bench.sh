@@ -7,7 +7,7 @@ STEPS=${2:-5}
 set -e
 for round in 1 2; do
   echo "== A ($round)"; timeout -k 10 300 python tools/time_conv.py
-  timeout -k 10 300 python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('A ms_per_step', d['ms_per_step'])"
+  timeout -k 10 300 python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-modes | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('A ms_per_step', d['ms_per_step'])"
   echo "== B ($round)"; MUNIT_HIP_LIB=$PWD/$ALT timeout -k 10 300 python tools/time_conv.py
-  MUNIT_HIP_LIB=$PWD/$ALT timeout -k 10 300 python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B ms_per_step', d['ms_per_step'])"
+  MUNIT_HIP_LIB=$PWD/$ALT timeout -k 10 300 python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-modes | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B ms_per_step', d['ms_per_step'])"
 done

@@ -11,8 +11,9 @@ recon_mask 1, aux losses 0), 256x256, batch 8, fp32.  N > 1 is weak scaling: eve
 per-GPU batch on its own shard of the global batch (data seed 7 + rank, identical model seed).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (forward implicit-GEMM conv on v_mfma_f32_32x32x2_f32) measured
-                  with HIP events around its launches in extra instrumented steps of this same run
+  roofline     -- dominant kernel (forward implicit-GEMM conv on v_mfma_f32_16x16x4_f32, direct-to-LDS tiles) measured
+                  with HIP events around its launches in extra instrumented steps of this same run; plus the
+                  step-level fractions on algorithmic and on executed FLOPs
   cpu_baseline -- the CPU oracle (oracle/munit_oracle.py, a torch-CPU restatement of the
                   reference step: kind "port") timed on this host's cores on a bounded sample
 """
@@ -57,49 +58,159 @@ def make_batch(batch, size, rank=0):
     return x_a, x_b, m_a, m_b
 
 
+PMC_SUMMARY = "profiles/r02_pmc_hbm_mfma.txt"
+
+
+def lib_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: ties a committed PMC summary to
+    the code it was collected on (the .so itself is not in git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "munit_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "munit_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "munit_hip.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md; bench.py cannot collect PMC itself).
-    Returns (bytes, source) or (None, None)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_pmc_hbm_mfma.txt")
+    The summary records the fingerprint of the kernel sources it was collected on; when the sources have changed since,
+    the figure is stale and (None, why) is returned.  Returns (bytes, source)."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
-        for line in open(path):
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None, "no PMC summary at %s" % PMC_SUMMARY
+    fp = [l.split()[-1] for l in lines if l.startswith("# kernel-source fingerprint:")]
+    if not fp or fp[0] != lib_fingerprint():
+        return None, "%s was collected on kernel sources %s, this run is %s: stale, not reported" % (
+            PMC_SUMMARY, fp[0] if fp else "unknown", lib_fingerprint())
+    try:
+        for line in lines:
             if line.startswith("conv_igemm_kernel<128, true, 0, 3>") and "blocks=   512" in line:
                 f = line.split()
                 fetch = float(f[f.index("fetch") + 1])
                 write = float(f[f.index("write") + 1])
-                return (fetch + write) * 1e6, "profiles/r01_h_pmc_hbm_mfma.txt (512-block launches: %.0f MB read + %.0f MB written)" % (fetch, write)
-    except (OSError, ValueError):
+                return (fetch + write) * 1e6, "%s (512-block launches: %.0f MB read + %.0f MB written)" % (PMC_SUMMARY, fetch, write)
+    except ValueError:
         pass
-    return None, None
+    return None, "dominant kernel not found in %s" % PMC_SUMMARY
 
 
-def cpu_baseline(size, seconds_budget=30.0):
-    """The oracle's dis_update + gen_update on the host cores, batch 1 at the bench resolution."""
+def host_cores():
+    """Physical cores of one socket (the CPU-baseline thread count SURVEY.md section 8d asks for)."""
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        sockets = len({p for p, _ in seen}) or 1
+        if seen:
+            return max(1, len(seen) // sockets)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(size, seconds_budget=45.0):
+    """The oracle's dis_update + gen_update on the host cores, batch 1: BASELINE.json configs[0] (128x128) and the bench
+    resolution; 1 warm-up + >= 3 timed steps each.  `value` is the bench-resolution sample."""
     from oracle import munit_oracle as O
     from tests.parity import oracle_states
-    hp = O.default_hp(size, 1, 1)
-    gen, dis_a, dis_b = oracle_states(hp, torch.float32)
-    orc = O.OracleTrainer(hp, gen, dis_a, dis_b)
-    x_a, x_b, m_a, m_b = O.synthetic_batch(1, size, seed=7)
+    cores = host_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
 
-    def one():
-        orc.update_learning_rate()
-        orc.dis_update(x_a, x_b)
-        orc.gen_update(x_a, x_b, m_a, m_b)
+    def sample(sz, budget):
+        hp = O.default_hp(sz, 1, 1)
+        gen, dis_a, dis_b = oracle_states(hp, torch.float32)
+        orc = O.OracleTrainer(hp, gen, dis_a, dis_b)
+        x_a, x_b, m_a, m_b = O.synthetic_batch(1, sz, seed=7)
 
-    one()  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if n >= 2 and el + el / n > seconds_budget or n >= 8:
-            break
-    el = time.perf_counter() - t0
-    return {"value": round(n / el, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/munit_oracle.py (torch %s CPU fp32), %dx%d batch 1, 1 warm-up + %d timed "
-                      "dis_update+gen_update steps" % (torch.__version__, size, size, n)}
+        def one():
+            orc.update_learning_rate()
+            orc.dis_update(x_a, x_b)
+            orc.gen_update(x_a, x_b, m_a, m_b)
+
+        one()  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if n >= 3 and (el + el / n > budget or n >= 8):
+                break
+        return n / (time.perf_counter() - t0), n
+
+    try:
+        v128, n128 = sample(128, seconds_budget / 4)
+        v, n = (v128, n128) if size == 128 else sample(size, seconds_budget)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(v, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/munit_oracle.py (torch %s CPU fp32, %d threads = physical cores of one socket), %dx%d batch "
+                      "1, 1 warm-up + %d timed dis_update+gen_update steps" % (torch.__version__, cores, size, size, n),
+            "config0_128x128_b1": {"value": round(v128, 4), "unit": "images/s", "timed_steps": n128}}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: run the N ranks as children of this (GPU-free) process through
+    torch.distributed.run, relay rank 0's JSON line on stdout (everything else goes to stderr) and return non-zero
+    if any rank failed or no line was produced."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    line_out = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            line_out = line.rstrip("\n")
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank failed (torch.distributed.run exit code %d)\n" % rc)
+        return rc
+    if line_out is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 1
+    print(line_out, flush=True)
+    return 0
+
+
+def dry_run(args, world, rank):
+    """--dry-run: rendezvous + one all-reduce on the CPU (gloo), no GPU work.  Checks the launch path (self-launch,
+    env contract, rank-0 JSON relay) on machines without a GPU; `value` is null."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2, float(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": None, "n_gpus": world, "steps": 0, "warmup": 0,
+                          "config": {"workload": "launcher check", "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -112,6 +223,7 @@ def main():
     ap.add_argument("--gen-state", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous on the CPU, no GPU work")
     ap.add_argument("--no-modes", action="store_true", help="skip the supplementary timing of the opt-in f32x3 mode")
     ap.add_argument("--precision", choices=["f32", "bf16", "f32x3"], default="f32",
                     help="f32 = the reference's arithmetic (the headline metric, BASELINE.json configs[1]); "
@@ -121,12 +233,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU yet
+        # (importing torch does not), and the ranks are CHILD processes -- never an exec of a GPU-initialised process.
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ       # under a launcher the RCCL group is built even for one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -152,19 +269,23 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         step()
+        marks[k + 1].record()        # on the caller's stream, which every update re-joins before it returns
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    per_step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -173,28 +294,37 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.batch * world * args.steps / elapsed
+    mode_txt = {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
+                "f32x3": "fp32 via exact 3-way bf16 split (6 product terms), fp32 accumulate"}[args.precision]
     out = {
         "metric": "images/sec (gen_update+dis_update) @%dx%d bs=%d" % (args.size, args.size, args.batch),
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "config_256.yaml AdaINGen_double+MsImageDis dis_update+gen_update, %dx%d, "
-                               "per-GPU batch %d, %s" % (args.size, args.size, args.batch,
-                                                         {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
-                                                          "f32x3": "fp32 via exact 3-way bf16 split (6 product terms), fp32 accumulate"}[args.precision]),
+                               "per-GPU batch %d, %s" % (args.size, args.size, args.batch, mode_txt),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "gen_state": args.gen_state, "loss_gen_total": round(loss_total, 5)},
+        "timing": {"method": "value = batch * n_gpus * steps / wall clock (max over ranks) between device-synchronised "
+                             "barriers, i.e. the MEAN step; ms_per_step_median = median of per-step HIP-event intervals "
+                             "on rank 0's stream in the same region",
+                   "ms_per_step_median": round(per_step_ms[len(per_step_ms) // 2], 3),
+                   "ms_per_step_min": round(per_step_ms[0], 3), "ms_per_step_max": round(per_step_ms[-1], 3)},
     }
 
-    if rank == 0 and not args.no_roofline and args.precision == "f32":
+    if not args.no_roofline and args.precision == "f32":
+        # Every rank runs these extra steps (they contain the gradient all-reduces, so the collectives must stay
+        # matched across ranks); rank 0 reports.
         step_flop = GFLOP_PER_PAIR_256 * 1e9 * (args.size / 256.0) ** 2 * args.batch
         # single-kernel timing: the instrumented steps run on one stream (in the timed region other kernels share
         # the chip with every launch, which stretches each launch's own duration while shortening the step)
         from munit_amd import trainer as trainer_mod
         saved = (ops.SIDE_STREAM_WGRAD, trainer_mod.BRANCH_STREAMS)
         ops.SIDE_STREAM_WGRAD = trainer_mod.BRANCH_STREAMS = False
-        step()
+        ops.FLOPS = {"alg": 0.0, "exec": 0.0}
+        step()                                   # also counts the FLOPs of one step, algorithmic and executed
         torch.cuda.synchronize()
+        flops, ops.FLOPS = ops.FLOPS, None
         ops.PROFILE = []
         for _ in range(2):
             step()
@@ -202,23 +332,29 @@ def main():
         recs, ops.PROFILE = ops.PROFILE, None
         ops.SIDE_STREAM_WGRAD, trainer_mod.BRANCH_STREAMS = saved
         sel = [(fl, e0.elapsed_time(e1)) for (tag, fl, e0, e1) in recs if tag == "conv_igemm_kernel<128,true,fwd>"]
-        if sel:
+        if sel and rank == 0:
             tot_fl = sum(f for f, _ in sel)
             tot_ms = sum(t for _, t in sel)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic_bytes()
+            sec = ms_per_step * 1e-3
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic_bytes()[0],
-                "traffic_source": pmc_traffic_bytes()[1],
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv_igemm_kernel<128,true,fwd> (forward implicit-GEMM conv, Cout>64, Cin%32==0)",
                 "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                 "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),
                 "method": "HIP events around every launch of the kernel in 2 extra instrumented steps after "
                           "the timed region, run on a single stream (the timed region overlaps kernels on 3 streams, "
                           "see step_frac); algorithmic FLOPs = 2*B*Ho*Wo*Cout*KH*KW*Cin per launch",
-                "step_achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
-                "step_frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_achieved": round(step_flop / sec / 1e12, 2),
+                "step_frac": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "step_algorithmic_tflop": round(step_flop / 1e12, 3),
+                # the same step counted launch by launch: algorithmic (cross-check of SURVEY.md 8d's figure) and the FLOPs
+                # the kernels really issue (sub-pixel up-sampling convs and box-sum backward-data execute fewer)
+                "step_counted_algorithmic_tflop": round(flops["alg"] / 1e12, 3),
+                "step_executed_tflop": round(flops["exec"] / 1e12, 3),
+                "step_executed_frac": round(flops["exec"] / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             }
     if rank == 0 and world == 1 and args.precision == "f32" and not args.no_modes:
         # supplementary, NOT the metric: the same step in the opt-in f32x3 mode (fp32 operands split exactly into three
@@ -251,7 +387,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.size)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -89,7 +89,32 @@ size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d);
 int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
                        float* db, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
 
-/* dx = dy * act'(y) for the fused activations (y = post-activation output). n elements. */
+/* Prepared weight images.  Two passes multiply by a re-laid-out image of the layer's weights: backward-data
+ * (flipped / transposed, one slice per stride phase: the autograd transpose of nn.Conv2d, networks.py:691-693) and the
+ * sub-pixel forward of the nearest-x2 + 5x5 decoder convs (networks.py:532-546; four merged 3x3 phase kernels).
+ * Weights change only at optimizer.step() (scripts/trainer.py:252-268), so the caller may keep these images: query
+ * the size (0 = the pass uses w as it is), fill a munit_prep_item on the host with munit_conv2d_prep_item, build
+ * the image with munit_conv2d_prepare_weights (one layer) or munit_conv2d_prepare_weights_batch (a table of items
+ * in DEVICE memory, one launch for every layer of an optimizer) and hand it to the *_prepared entry points.  With
+ * wp == NULL those behave exactly like munit_conv2d_fwd / _dgrad (image rebuilt into the workspace per call). */
+enum { MUNIT_PASS_FWD = 0, MUNIT_PASS_DGRAD = 1, MUNIT_PASS_WGRAD = 2 };
+enum { MUNIT_PREP_NONE = 0, MUNIT_PREP_DGRAD = 1, MUNIT_PREP_SUBPIXEL = 2 };
+typedef struct {
+  const float* w; /* [Cout][KH][KW][Cin] */
+  float* wp;      /* image, munit_conv2d_prepared_weight_bytes() bytes */
+  int Cout, KH, KW, Cin;
+  int kind;       /* MUNIT_PREP_* */
+  int ps;         /* stride phases per axis (MUNIT_PREP_DGRAD) */
+} munit_prep_item;
+size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, int pass);
+int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const float* w, float* wp, munit_prep_item* out);
+int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream);
+int munit_conv2d_prepare_weights_batch(const munit_prep_item* items_dev, int n, munit_stream_t stream);
+int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* x, const float* w, const float* wp,
+                              const float* bias, float* y, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float* dy, const float* w, const float* wp,
+                                const float* add, float* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
+
 /* nn.Linear of LinearBlock (scripts/networks.py:712, 743-749) under its own name: y[B][N] = act(x[B][K] w[N][K]^T + bias),
  * i.e. the 1x1 convolution on a [B][1][1][K] image (same kernels).  bwd: dx (or NULL), dw = beta*dw + dy^T x and
  * db likewise (or NULL); dy is the gradient at the PRE-activation output (apply munit_act_bwd first). */
@@ -99,6 +124,14 @@ int munit_linear_fwd(const float* x, const float* w, const float* bias, float* y
 int munit_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int K,
                      int N, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
 
+/* FLOPs (2 x multiply-accumulates over valid GEMM rows) the kernels ISSUE for one call of the pass, next to the
+ * algorithmic 2*B*Ho*Wo*Cout*KH*KW*Cin of the torch op it replaces (nn.Conv2d / its autograd, networks.py:691-693):
+ * the sub-pixel form of the up-sampling convs and the box-sum backward-data execute fewer, strided backward-data over
+ * the padded domain and the 4-channel re-layout of the 3-channel image layers slightly more.  Measurement only
+ * (bench.py: roofline.step_executed_tflop). */
+double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass);
+
+/* dx = dy * act'(y) for the fused activations (y = post-activation output). n elements. */
 int munit_act_bwd(int act, float slope, const float* y, const float* dy, float* dx, size_t n,
                   munit_stream_t stream);
 

@@ -25,6 +25,12 @@ class ConvDesc(Structure):
                 ("upsample", c_int), ("act", c_int), ("slope", c_float), ("compute", c_int)]
 
 
+class PrepItem(Structure):
+    """munit_prep_item."""
+    _fields_ = [("w", c_void_p), ("wp", c_void_p), ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("Cin", c_int),
+                ("kind", c_int), ("ps", c_int)]
+
+
 class ImageDesc(Structure):
     """munit_image_desc."""
     _fields_ = [("src_off", ctypes.c_longlong), ("src_h", c_int), ("src_w", c_int), ("rs_h", c_int), ("rs_w", c_int),
@@ -45,6 +51,13 @@ SIGNATURES = {
     "munit_conv2d_dgrad": (c_int, [_DESC, _P, _P, _P, _P, _P, c_size_t, _P]),
     "munit_conv2d_wgrad_workspace_bytes": (c_size_t, [_DESC]),
     "munit_conv2d_wgrad": (c_int, [_DESC, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "munit_conv2d_prepared_weight_bytes": (c_size_t, [_DESC, c_int]),
+    "munit_conv2d_prep_item": (c_int, [_DESC, c_int, _P, _P, POINTER(PrepItem)]),
+    "munit_conv2d_prepare_weights": (c_int, [POINTER(PrepItem), _P]),
+    "munit_conv2d_prepare_weights_batch": (c_int, [_P, c_int, _P]),
+    "munit_conv2d_fwd_prepared": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "munit_conv2d_dgrad_prepared": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "munit_conv2d_executed_flops": (c_double, [_DESC, c_int]),
     "munit_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "munit_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "munit_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),

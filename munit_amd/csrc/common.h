@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "../../include/munit_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,6 +27,10 @@ void munit_set_error(const char* fmt, ...);
       return MUNIT_ERR_LAUNCH;                                                     \
     }                                                                              \
   } while (0)
+
+// Debug switches (MUNIT_DEBUG_*) are read ONCE per process: getenv on every launch path is host time that all eight
+// data-parallel ranks pay on every one of ~5 k launches per step.
+#define MUNIT_ENV_FLAG(name) ([]() -> bool { static const bool v_ = getenv(name) != nullptr; return v_; }())
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -54,6 +59,9 @@ __device__ inline int src_coord(int v, int Hu, int ups, int reflect) {
   r = reflect ? r : (inside ? v : -1);
   return r < 0 ? -1 : (r >> ups);
 }
+
+// conv_igemm.hip: executed (not algorithmic) FLOPs of the forward / backward-data pass of a layer
+double munit_igemm_executed_flops(const munit_conv_desc* d, int pass);
 
 // conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side
 bool munit_small_fwd_supported(const munit_conv_desc* d);

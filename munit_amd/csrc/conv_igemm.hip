@@ -1,17 +1,17 @@
-// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
-// v_mfma_f32_32x32x2_f32.  One kernel serves
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32
+// (bf16 / f32x3 modes: v_mfma_f32_16x16x32_bf16).  One kernel serves
 //   * forward conv (reflect/zero pad, stride 1/2, optional fused nearest x2 upsample of
 //     the input, fused bias + activation)            -- networks.py:695-701, 532-546
-//   * backward-data, as a stride-1 zero-padded correlation of dy with re-laid-out weights,
-//     one launch "phase" per (row,col) residue for strided convs (a transposed conv);
-//     the adjoint of the reflect padding / upsample is applied by fold_kernel.
+//   * backward-data: stride-1 layers with the pad/upsample adjoint folded into the gather (ROLE 2), strided
+//     layers as one launch "phase" per (row,col) residue (a transposed conv) + fold_kernel (ROLE 1).
 //
 // GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin with k = (kh*KW+kw)*Cin+ci.
 // NHWC makes every K-tile of 32 channels one contiguous 128-byte run per output pixel.
-// Tile: 128 (M) x BN (N) x 32 (K), 256 threads = 4 waves in 2x2, each wave 64 x BN/2
-// as 32x32 MFMA tiles.  A/B tiles are staged through LDS as [row][36] floats (pad 4 =>
-// conflict-free ds_read_b128 for the MFMA operand fetch: one b128 feeds 4 MFMA k-steps).
-// Global loads for tile k+1 are issued before the MFMAs of tile k (register prefetch).
+// Tile: 128 (M) x BN (N) x 32 (K), 512 threads = 8 waves (4 x 2 at BN=128), each wave 32 channels x 64 or 32
+// pixels as 16x16 MFMA tiles.  fp32 single-gather variants fill the LDS tiles directly from global memory
+// (global_load_lds_dwordx4, XOR-swizzled unpadded [row][32] tiles); the folded backward-data and the bf16 modes
+// stage through registers into [row][36] (pad 4 => conflict-free ds_read_b128: one b128 feeds 4 MFMA k-steps).
+// Tiles are double-buffered with one barrier per K-tile.  DESIGN.md section 3.1.
 #include "common.h"
 #include <cstdlib>
 
@@ -664,55 +664,74 @@ __global__ void splitk_epilogue_kernel(IgemmParams p, int phases) {
   }
 }
 
-// Re-lay-out weights for backward-data.  w: [Cout][KH][KW][Cin]  ->
-// wt: [ps*ps phases][Cin][T][T][Cout] with T = K/ps and, for phase (pa,pb), tap (t,r):
+// ---- prepared weights -------------------------------------------------------------------------------------
+// Two layers of the path multiply by a re-laid-out image of their weights: backward-data (flipped / transposed,
+// one slice per stride phase) and the sub-pixel forward of the up-sampling convs (merged phase weights).  Weights
+// only change at the optimizer step, so the caller may keep these images (munit_conv2d_prepare_weights[_batch])
+// and pass them to the *_prepared entry points; without one the image is rebuilt into the workspace per call.
+typedef munit_prep_item PrepItem;
+
+// backward-data: w [Cout][KH][KW][Cin] -> wt [ps*ps phases][Cin][T][T][Cout], T = K/ps, phase (pa,pb), tap (t,r):
 //   wt[ph][ci][t][r][co] = w[co][pa + ps*(T-1-t)][pb + ps*(T-1-r)][ci]
-__global__ void wt_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int KH,
-                                int KW, int Cin, int ps) {
-  const int TH = KH / ps, TW = KW / ps;
-  const long long per_phase = (long long)Cin * TH * TW * Cout;
-  const long long total = per_phase * ps * ps;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    long long r_ = i;
-    int co = (int)(r_ % Cout); r_ /= Cout;
-    int r = (int)(r_ % TW); r_ /= TW;
-    int t = (int)(r_ % TH); r_ /= TH;
-    int ci = (int)(r_ % Cin); r_ /= Cin;
-    int ph = (int)r_;
-    int pa = ph / ps, pb = ph % ps;
-    int kh = pa + ps * (TH - 1 - t);
-    int kw = pb + ps * (TW - 1 - r);
-    wt[i] = w[(((long long)co * KH + kh) * KW + kw) * Cin + ci];
-  }
+__device__ inline void prep_dgrad_elem(const PrepItem& it, long long i) {
+  const int ps = it.ps, TH = it.KH / ps, TW = it.KW / ps;
+  long long r_ = i;
+  int co = (int)(r_ % it.Cout); r_ /= it.Cout;
+  int r = (int)(r_ % TW); r_ /= TW;
+  int t = (int)(r_ % TH); r_ /= TH;
+  int ci = (int)(r_ % it.Cin); r_ /= it.Cin;
+  int ph = (int)r_;
+  int pa = ph / ps, pb = ph % ps;
+  int kh = pa + ps * (TH - 1 - t);
+  int kw = pb + ps * (TW - 1 - r);
+  it.wp[i] = it.w[(((long long)co * it.KH + kh) * it.KW + kw) * it.Cin + ci];
 }
 
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv: output pixel (2i+a, 2j+b) reads source rows
 // i-1, i, i+1 with the 5 kernel rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (same for
 // columns), so each of the 4 phases is a 3x3 conv over the source with summed weights: 36 instead of
 // 100 MACs per source pixel and channel pair.  wc: [phase = a*2+b][Cout][3][3][Cin].
-__global__ void upw_combine_kernel(const float* __restrict__ w, float* __restrict__ wc, int Cout, int Cin) {
-  const long long per_phase = (long long)Cout * 9 * Cin;
-  const long long total = 4 * per_phase;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    long long r = i;
-    const int ci = (int)(r % Cin); r /= Cin;
-    const int dw = (int)(r % 3); r /= 3;
-    const int dh = (int)(r % 3); r /= 3;
-    const int co = (int)(r % Cout); r /= Cout;
-    const int ph = (int)r;
-    const int a = ph >> 1, b = ph & 1;
-    // kernel rows merged into tap dh of phase a: first row and count
-    const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
-    const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
-    const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
-    const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
-    float s = 0.f;
-    for (int kh = h0; kh < h0 + hn; ++kh)
-      for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)co * 5 + kh) * 5 + kw) * Cin + ci];
-    wc[i] = s;
+__device__ inline void prep_subpixel_elem(const PrepItem& it, long long i) {
+  long long r = i;
+  const int ci = (int)(r % it.Cin); r /= it.Cin;
+  const int dw = (int)(r % 3); r /= 3;
+  const int dh = (int)(r % 3); r /= 3;
+  const int co = (int)(r % it.Cout); r /= it.Cout;
+  const int ph = (int)r;
+  const int a = ph >> 1, b = ph & 1;
+  // kernel rows merged into tap dh of phase a: first row and count
+  const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
+  const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
+  const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
+  const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
+  float s = 0.f;
+  for (int kh = h0; kh < h0 + hn; ++kh)
+    for (int kw = w0; kw < w0 + wn; ++kw) s += it.w[(((long long)co * 5 + kh) * 5 + kw) * it.Cin + ci];
+  it.wp[i] = s;
+}
+
+__host__ __device__ inline long long prep_elems(const PrepItem& it) {
+  return it.kind == MUNIT_PREP_SUBPIXEL ? (long long)4 * 9 * it.Cout * it.Cin : (long long)it.Cout * it.KH * it.KW * it.Cin;
+}
+
+// blockIdx.y = item (DEV: table in device memory, one launch re-lays every weight of an optimizer; else the one
+// item passed by value), grid-stride over the item's elements in x
+template <bool DEV>
+__global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem one) {
+  const PrepItem it = DEV ? items[blockIdx.y] : one;
+  const long long total = prep_elems(it);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
+    else prep_dgrad_elem(it, i);
   }
+}
+
+int launch_prep_one(const PrepItem& it, hipStream_t st) {
+  const long long total = prep_elems(it);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(prep_weights_kernel<false>, dim3(blocks), dim3(256), 0, st, nullptr, it);
+  MUNIT_CHECK_LAUNCH("prep_weights");
+  return MUNIT_OK;
 }
 
 // Adjoint of (nearest x2 upsample) + (reflect | zero pad): gather-sum the padded-domain
@@ -820,7 +839,7 @@ int pick_ksplit(int M, int Cout, int Ktot, int phases) {
   const int bn = Cout <= 64 ? 64 : 128;
   const int tiles = cdiv(M, BM) * cdiv(Cout, bn) * phases;
   const int nk = cdiv(Ktot, BK);
-  if (tiles >= 192 || nk < 16 || getenv("MUNIT_DEBUG_NO_SPLITK")) return 1;
+  if (tiles >= 192 || nk < 16 || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SPLITK")) return 1;
   int ks = std::min(cdiv(512, tiles), nk / 4);
   return std::max(1, std::min(ks, 32));
 }
@@ -862,7 +881,7 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2>), grid, block, 0, st, q);
     }
-  } else if (aligned && p.ct == 0 && NWAVES == 8 && !getenv("MUNIT_DEBUG_NO_DMA")) {
+  } else if (aligned && p.ct == 0 && NWAVES == 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_DMA")) {
     // single-gather fp32 variants: tiles go global -> LDS directly
     if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 3>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 3>), grid, block, 0, st, q);
@@ -919,7 +938,7 @@ namespace {
 bool subpixel_ok(const munit_conv_desc* d) {
   return d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
          d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 32 == 0 && d->H >= 3 && d->W >= 3 &&
-         !getenv("MUNIT_DEBUG_NO_SUBPIXEL");
+         !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SUBPIXEL");
 }
 }  // namespace
 
@@ -936,12 +955,18 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
 extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w,
                                 const float* bias, float* y, void* ws, size_t ws_bytes,
                                 munit_stream_t stream) {
+  return munit_conv2d_fwd_prepared(d, x, w, nullptr, bias, y, ws, ws_bytes, stream);
+}
+
+extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* x, const float* w, const float* wp,
+                                         const float* bias, float* y, void* ws, size_t ws_bytes,
+                                         munit_stream_t stream) {
   int Ho, Wo;
   int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (munit_small_fwd_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_FWD"))
+  if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD"))
     return munit_small_fwd(d, Ho, Wo, x, w, bias, y, st);
   IgemmParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
@@ -967,12 +992,12 @@ extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const 
       munit_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
       return MUNIT_ERR_WORKSPACE;
     }
-    float* wc = reinterpret_cast<float*>(ws);
-    {
-      long long total = (long long)4 * 9 * d->Cout * d->Cin;
-      int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-      hipLaunchKernelGGL(upw_combine_kernel, dim3(blocks), dim3(256), 0, st, w, wc, d->Cout, d->Cin);
-      MUNIT_CHECK_LAUNCH("upw_combine");
+    const float* wc = wp;
+    if (wc == nullptr) {   // no prepared image from the caller: merge the phase weights into the workspace
+      PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_SUBPIXEL, 1};
+      rc = launch_prep_one(it, st);
+      if (rc) return rc;
+      wc = it.wp;
     }
     IgemmParams q = p;
     q.w = wc;
@@ -1066,12 +1091,12 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     munit_conv_desc t{};
     t.B = d->B; t.H = pl->Ho; t.W = pl->Wo; t.Cin = d->Cout; t.Cout = d->Cin; t.KH = pl->TH; t.KW = pl->TW;
     t.stride = 1; t.pad = pl->TH - 1; t.pad_mode = MUNIT_PAD_ZERO;
-    pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t) && !getenv("MUNIT_DEBUG_NO_SMALL_DGRAD");
+    pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_DGRAD");
     if (pl->small) pl->folded = false;
-    if (getenv("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
+    if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
   }
   pl->boxsum = pl->folded && d->upsample == 1 && d->KH == 5 && d->pad == 2 && reflect && d->Cout % 32 == 0 &&
-               d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !getenv("MUNIT_DEBUG_NO_BOXSUM");
+               d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_BOXSUM");
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
@@ -1096,24 +1121,29 @@ extern "C" size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d) {
 extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w,
                                   const float* add, float* dx, void* ws, size_t ws_bytes,
                                   munit_stream_t stream) {
+  return munit_conv2d_dgrad_prepared(d, dy, w, nullptr, add, dx, ws, ws_bytes, stream);
+}
+
+extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float* dy, const float* w, const float* wp,
+                                           const float* add, float* dx, void* ws, size_t ws_bytes,
+                                           munit_stream_t stream) {
   DgradPlan pl;
   int rc = plan_dgrad(d, &pl);
   if (rc) return rc;
-  MUNIT_CHECK_ARG(dy && w && dx && ws, "conv2d_dgrad: null pointer");
+  MUNIT_CHECK_ARG(dy && (w || wp) && dx && ws, "conv2d_dgrad: null pointer");
   if (ws_bytes < pl.wt_bytes + pl.g_bytes + pl.sk_bytes) {
     munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes + pl.sk_bytes);
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  float* wt = reinterpret_cast<float*>(ws);
+  const float* wt = wp;
   float* g = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.wt_bytes);
   const bool direct = pl.direct && add == nullptr;
-  {
-    long long total = (long long)d->Cout * d->KH * d->KW * d->Cin;
-    int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(wt_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w, wt, d->Cout, d->KH, d->KW,
-                       d->Cin, pl.ps);
-    MUNIT_CHECK_LAUNCH("wt_dgrad");
+  if (wt == nullptr) {   // no prepared image from the caller: re-lay the weights into the workspace
+    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_DGRAD, pl.ps};
+    rc = launch_prep_one(it, st);
+    if (rc) return rc;
+    wt = it.wp;
   }
   {
     // data gradient of a 7x7 conv with 3 input channels (first encoder layers): the padded-domain
@@ -1221,6 +1251,71 @@ extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, con
     MUNIT_CHECK_LAUNCH("fold");
   }
   return MUNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Prepared weight images (see prep_weights_kernel)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const float* w, float* wp, munit_prep_item* out) {
+  int Ho, Wo;
+  int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
+  if (rc) return rc;
+  MUNIT_CHECK_ARG(out != nullptr, "conv2d_prep_item: null item");
+  MUNIT_CHECK_ARG(pass == MUNIT_PASS_FWD || pass == MUNIT_PASS_DGRAD, "conv2d_prep_item: pass must be MUNIT_PASS_FWD or _DGRAD");
+  munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1};
+  if (pass == MUNIT_PASS_FWD) {
+    if (subpixel_ok(d)) it.kind = MUNIT_PREP_SUBPIXEL;
+  } else {
+    DgradPlan pl;
+    rc = plan_dgrad(d, &pl);
+    if (rc) return rc;
+    it.kind = MUNIT_PREP_DGRAD;
+    it.ps = pl.ps;
+  }
+  *out = it;
+  return MUNIT_OK;
+}
+
+extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, int pass) {
+  munit_prep_item it;
+  if (munit_conv2d_prep_item(d, pass, nullptr, nullptr, &it) || it.kind == MUNIT_PREP_NONE) return 0;
+  return (size_t)prep_elems(it) * sizeof(float);
+}
+
+extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
+  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL, "conv2d_prepare_weights: bad kind %d", item->kind);
+  MUNIT_CHECK_ARG(item->ps >= 1 && item->KH % item->ps == 0 && item->KW % item->ps == 0, "conv2d_prepare_weights: bad phase count");
+  MUNIT_CHECK_ARG(item->kind != MUNIT_PREP_SUBPIXEL || (item->KH == 5 && item->KW == 5), "conv2d_prepare_weights: sub-pixel needs 5x5");
+  return launch_prep_one(*item, (hipStream_t)stream);
+}
+
+extern "C" int munit_conv2d_prepare_weights_batch(const munit_prep_item* items_dev, int n, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(items_dev != nullptr && n > 0 && n <= 65535, "conv2d_prepare_weights_batch: bad table (n=%d)", n);
+  hipLaunchKernelGGL(prep_weights_kernel<true>, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, items_dev, PrepItem{});
+  MUNIT_CHECK_LAUNCH("prep_weights_batch");
+  return MUNIT_OK;
+}
+
+// Multiply-accumulates the kernels actually issue for one call (x2 = FLOPs), as opposed to the algorithmic
+// 2*B*Ho*Wo*Cout*KH*KW*Cin: the sub-pixel forward runs 4 merged 3x3 phases + the 25-tap frame, the box-sum
+// backward-data one 25-tap row per interior SOURCE pixel + the frame, strided backward-data its phases over the
+// padded domain.  Valid GEMM rows only (tile padding is not counted).  bench.py reports both totals.
+double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
+  int Ho, Wo;
+  if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
+  const double cc = 2.0 * d->Cin * d->Cout;
+  if (pass == MUNIT_PASS_FWD) {
+    if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    return cc * d->B * Ho * Wo * d->KH * d->KW;
+  }
+  DgradPlan pl;
+  if (plan_dgrad(d, &pl)) return 0.0;
+  if (pl.boxsum) return cc * d->B * ((double)(d->H - 4) * (d->W - 4) + 4.0 * d->W + 4.0 * (d->H - 4)) * d->KH * d->KW;
+  if (pl.folded) return cc * d->B * d->H * d->W * d->KH * d->KW;
+  if (pl.direct) return cc * d->B * Ho * Wo * d->KH * d->KW;
+  // phase launches over the padded domain (also the 3-channel first layer through the thread-per-pixel kernel)
+  return cc * d->B * (double)(pl.Ho + pl.TH - 1) * (pl.Wo + pl.TW - 1) * pl.TH * pl.TW * pl.ps * pl.ps;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -697,7 +697,7 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   // FAST loader: 32-bit byte offsets and 24-bit multiplies (see the kernel)
   const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, db_ = (long long)p.B * p.dy_sb * 4;
   const bool fast = aligned && (p.Cout % 4 == 0) && !p.frame && xb < (1ll << 31) && db_ < (1ll << 31) &&
-                    (long long)p.B * p.H * p.W < (1ll << 23) && !getenv("MUNIT_DEBUG_NO_FAST_WGRAD");
+                    (long long)p.B * p.H * p.W < (1ll << 23) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD");
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
   if (fast && p.ct == 1) {
@@ -731,7 +731,7 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
 }
 
 bool cin3_padded_ok(const munit_conv_desc* d) {
-  return d->Cin == 3 && d->Cout % 4 == 0 && d->upsample == 0 && !getenv("MUNIT_DEBUG_NO_CIN3_PAD");
+  return d->Cin == 3 && d->Cout % 4 == 0 && d->upsample == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_CIN3_PAD");
 }
 struct Cin3Plan {
   WgradPlan pl;
@@ -746,7 +746,7 @@ void plan_cin3(const munit_conv_desc* d, int Ho, int Wo, Cin3Plan* cp) {
 bool subpixel_wgrad_ok(const munit_conv_desc* d) {
   return d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
          d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 4 == 0 && d->H >= 3 && d->W >= 3 &&
-         !getenv("MUNIT_DEBUG_NO_SUBPIXEL");
+         !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SUBPIXEL");
 }
 
 // sub-pixel wgrad of an up-sampling conv: workspace = [dwc: 4*Cout*9*Cin][slabs of the largest launch]
@@ -768,7 +768,7 @@ void plan_subpixel(const munit_conv_desc* d, SubpixelPlan* sp) {
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
-  if (munit_small_wgrad_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, Ho);
+  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, Ho);
   if (subpixel_wgrad_ok(d)) {
     SubpixelPlan sp;
     plan_subpixel(d, &sp);
@@ -784,6 +784,18 @@ extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   return pl.slab_bytes + pl.bias_bytes;
 }
 
+extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass) {
+  if (pass == MUNIT_PASS_FWD || pass == MUNIT_PASS_DGRAD) return munit_igemm_executed_flops(d, pass);
+  int Ho, Wo;
+  if (pass != MUNIT_PASS_WGRAD || munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
+  const double cc = 2.0 * d->Cin * d->Cout;
+  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return cc * d->B * Ho * Wo * d->KH * d->KW;
+  if (subpixel_wgrad_ok(d))   // 4 phase gradients over the interior source pixels + the 25-tap frame
+    return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+  if (cin3_padded_ok(d)) return 2.0 * 4 * d->Cout * d->B * Ho * Wo * d->KH * d->KW;   // zero 4th input channel
+  return cc * d->B * Ho * Wo * d->KH * d->KW;
+}
+
 extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
                                   float* db, float beta, void* ws, size_t ws_bytes,
                                   munit_stream_t stream) {
@@ -796,7 +808,7 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (munit_small_wgrad_supported(d) && !getenv("MUNIT_DEBUG_NO_SMALL_WGRAD"))
+  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD"))
     return munit_small_wgrad(d, Ho, Wo, x, dy, dw, db, beta, ws, st);
   const bool aligned = d->Cin % 4 == 0;
   WgradParams p{};

@@ -23,6 +23,19 @@ _ws_cache = {}
 # bench.py sets this to a list to time every forward-conv launch with HIP events on the launch stream:
 # entries are (kernel variant tag, algorithmic FLOPs, start event, end event).
 PROFILE = None
+# tests/parity.py sets this to a list to record, in call order, the sign pattern (output > 0) behind every ReLU /
+# LeakyReLU of a forward pass, so that the fp64 oracle can take the same branch at every kink.
+MASK_SINK = None
+# bench.py sets this to {"alg": 0.0, "exec": 0.0} to add up, over one step, the algorithmic FLOPs of every convolution /
+# linear pass (SURVEY.md section 8d's definition) and the FLOPs the kernels actually issue (sub-pixel and box-sum
+# forms execute fewer).
+FLOPS = None
+
+
+def _count(pl, which):
+    if FLOPS is not None:
+        FLOPS["alg"] += pl.flop
+        FLOPS["exec"] += pl.flop_exec[which]
 
 
 # Arithmetic of the conv / linear contractions: "f32" (exact fp32 MFMA, the reference's arithmetic) or "bf16"
@@ -90,62 +103,159 @@ def workspace(nbytes, device):
     return buf
 
 
-def _desc(x, weight, stride, pad, pad_type, upsample, act="none", slope=0.2):
-    b, cin, h, w = x.shape
-    cout, cin_w, kh, kw = weight.shape
-    if cin_w != cin:
-        raise RuntimeError("munit_amd.conv2d: weight expects %d input channels, input has %d" % (cin_w, cin))
-    return ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), ACT[act],
-                    float(slope), _COMPUTE)
+class _Plan(object):
+    """Everything about one layer geometry that does not change between calls: the descriptor, output extent,
+    workspace sizes and prepared-weight sizes of the three passes.  Built once per (shape, config) -- the C-ABI
+    queries behind it cost more host time than the launch itself when they are repeated ~500 times per step."""
+    __slots__ = ("d", "ref", "ho", "wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "prep_bytes", "tag", "flop", "flop_exec")
 
 
-def _out_hw(d):
+_plans = {}
+
+
+def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none", slope=0.2):
+    key = (b, h, w, cin, cout, kh, kw, stride, pad, pad_type, bool(upsample), act, slope, _COMPUTE)
+    pl = _plans.get(key)
+    if pl is not None:
+        return pl
     lib = _lib.load()
+    pl = _Plan()
+    pl.d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), ACT[act],
+                    float(slope), _COMPUTE)
+    pl.ref = byref(pl.d)
     ho, wo = c_int(), c_int()
-    _lib.check(lib.munit_conv2d_out_hw(byref(d), byref(ho), byref(wo)), "conv2d_out_hw")
-    return ho.value, wo.value
+    _lib.check(lib.munit_conv2d_out_hw(pl.ref, byref(ho), byref(wo)), "conv2d_out_hw")
+    pl.ho, pl.wo = ho.value, wo.value
+    pl.ws_fwd = lib.munit_conv2d_fwd_workspace_bytes(pl.ref)
+    pl.ws_dgrad = lib.munit_conv2d_dgrad_workspace_bytes(pl.ref)
+    pl.ws_wgrad = lib.munit_conv2d_wgrad_workspace_bytes(pl.ref)
+    pl.prep_bytes = (lib.munit_conv2d_prepared_weight_bytes(pl.ref, 0), lib.munit_conv2d_prepared_weight_bytes(pl.ref, 1))
+    pl.tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if cout <= 64 else 128, "true" if cin % 32 == 0 else "false")
+    if pl.ws_fwd:
+        pl.tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
+    elif cout <= 4:
+        pl.tag = "conv_patch_fwd_kernel"
+    pl.flop = 2.0 * b * pl.ho * pl.wo * cout * kh * kw * cin        # algorithmic, the same for all three passes
+    pl.flop_exec = tuple(lib.munit_conv2d_executed_flops(pl.ref, k) for k in range(3))
+    _plans[key] = pl
+    return pl
+
+
+def _on(t):
+    """Context for launching on t's device: kernels and streams are per device, the process-wide current device may
+    be another one (trainer on cuda:N without torch.cuda.set_device(N))."""
+    return torch.cuda.device_of(t)
+
+
+def _same_device(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("munit_amd: operands live on different devices (%s vs %s)" % (dev, t.device))
+
+
+def _guarded(fn):
+    """Run a Function.forward / backward on the device of its first tensor argument (see _on)."""
+    def wrapper(ctx, t, *args):
+        with torch.cuda.device_of(t):
+            return fn(ctx, t, *args)
+    return wrapper
+
+
+# ------------------------------------------------------------------------------------------
+# prepared weight images (include/munit_hip.h: munit_conv2d_prepare_weights*)
+# ------------------------------------------------------------------------------------------
+def _prepared(owner, w, pl, which):
+    """Image of `w` for pass `which` (0 forward, 1 backward-data) kept with the parameter `owner`, or None when the
+    pass needs none / the parameter is not bound to a flat optimizer buffer (then the library rebuilds the image in
+    the workspace on every call).  Images are refreshed in ONE launch by the optimizer after every step
+    (FusedAdam.refresh_prepared); here only first use and in-place edits of the parameter (load_state_dict) rebuild."""
+    if owner is None or not pl.prep_bytes[which]:
+        return None
+    reg = getattr(owner, "_munit_prep", None)
+    if reg is None or w.data_ptr() != owner.data_ptr():
+        return None
+    ent = reg.get(which)
+    ver = owner._version
+    if ent is not None and ent[1] == ver:
+        return ent[0]
+    lib = _lib.load()
+    fresh = ent is None
+    if fresh:
+        buf = torch.empty(pl.prep_bytes[which] // 4, dtype=torch.float32, device=w.device)
+        item = _lib.PrepItem()
+        _lib.check(lib.munit_conv2d_prep_item(pl.ref, which, _p(w), _p(buf), byref(item)), "conv2d_prep_item")
+        ent = [buf, ver, item]
+        reg[which] = ent
+    _lib.check(lib.munit_conv2d_prepare_weights(byref(ent[2]), _stream()), "conv2d_prepare_weights")
+    ent[1] = ver
+    # other streams may use the image right away (the a / b branches share the style encoder): rare path, so simply
+    # finish it before returning instead of carrying an event per parameter
+    torch.cuda.current_stream().synchronize()
+    if fresh:
+        opt = getattr(owner, "_munit_opt", None)
+        if opt is not None:
+            opt.register_prepared(ent[2])
+    return ent[0]
+
+
+def prepare_weights_batch(table, n):
+    """table: device uint8 tensor holding n munit_prep_item structs."""
+    lib = _lib.load()
+    with _on(table):
+        _lib.check(lib.munit_conv2d_prepare_weights_batch(_p(table), n, _stream()), "conv2d_prepare_weights_batch")
 
 
 # ------------------------------------------------------------------------------------------
 # raw (non-autograd) entry points, also used by the tests
 # ------------------------------------------------------------------------------------------
-def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=0.2):
+def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=0.2, owner=None):
     lib = _lib.load()
     x, weight = nhwc(x), nhwc(weight)
-    d = _desc(x, weight, stride, pad, pad_type, upsample, act, slope)
-    ho, wo = _out_hw(d)
-    y = empty_nhwc(x.shape[0], weight.shape[0], ho, wo, x)
-    nbytes = lib.munit_conv2d_fwd_workspace_bytes(byref(d))
-    ws = workspace(nbytes, x.device) if nbytes else None
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(lib.munit_conv2d_fwd(byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws),
-                                    ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
-    if PROFILE is not None:
-        e1.record()
-        tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if d.Cout <= 64 else 128, "true" if d.Cin % 32 == 0 else "false")
-        if nbytes:
-            tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
-        elif d.Cout <= 4:
-            tag = "conv_patch_fwd_kernel"
-        PROFILE.append((tag, 2.0 * d.B * ho * wo * d.Cout * d.KH * d.KW * d.Cin, e0, e1))
+    _same_device(x, weight, bias)
+    b, cin, h, w = x.shape
+    cout, cin_w, kh, kw = weight.shape
+    if cin_w != cin:
+        raise RuntimeError("munit_amd.conv2d: weight expects %d input channels, input has %d" % (cin_w, cin))
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act, slope)
+    with _on(x):
+        y = empty_nhwc(b, cout, pl.ho, pl.wo, x)
+        ws = workspace(pl.ws_fwd, x.device) if pl.ws_fwd else None
+        wp = _prepared(owner, weight, pl, 0)
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.munit_conv2d_fwd_prepared(pl.ref, _p(x), _p(weight), _p(wp), _p(bias), _p(y), _p(ws),
+                                                 ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((pl.tag, pl.flop, e0, e1))
+        _count(pl, 0)
+    if MASK_SINK is not None and act in ("relu", "lrelu"):
+        MASK_SINK.append(y > 0)
     return y
 
 
-def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=None):
+def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=None, owner=None):
     lib = _lib.load()
     dy, weight = nhwc(dy), nhwc(weight)
+    _same_device(dy, weight, add)
     b, cin, h, w = x_shape
     cout, _, kh, kw = weight.shape
-    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0, _COMPUTE)
-    nbytes = lib.munit_conv2d_dgrad_workspace_bytes(byref(d))
-    ws = workspace(nbytes, dy.device)
-    dx = empty_nhwc(b, cin, h, w, dy)
-    if add is not None:
-        add = nhwc(add)
-    _lib.check(lib.munit_conv2d_dgrad(byref(d), _p(dy), _p(weight), _p(add), _p(dx), _p(ws), ws.numel(), _stream()),
-               "conv2d_dgrad")
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample)
+    with _on(dy):
+        ws = workspace(pl.ws_dgrad, dy.device)
+        dx = empty_nhwc(b, cin, h, w, dy)
+        if add is not None:
+            add = nhwc(add)
+        wp = _prepared(owner, weight, pl, 1)
+        _lib.check(lib.munit_conv2d_dgrad_prepared(pl.ref, _p(dy), _p(weight), _p(wp), _p(add), _p(dx), _p(ws),
+                                                   ws.numel(), _stream()), "conv2d_dgrad")
+        _count(pl, 1)
     return dx
 
 
@@ -154,26 +264,29 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
     """dw/db given -> accumulate (beta) in place; else fresh tensors are returned."""
     lib = _lib.load()
     x, dy = nhwc(x), nhwc(dy)
+    _same_device(x, dy, dw, db)
     b, cin, h, w = x.shape
     cout, _, kh, kw = weight_shape
-    d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), 0, 0.0, _COMPUTE)
-    nbytes = lib.munit_conv2d_wgrad_workspace_bytes(byref(d))
-    ws = workspace(nbytes, x.device)
-    if dw is None:
-        dw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32,
-                         memory_format=torch.channels_last)
-        beta = 0.0
-    if db is None and want_bias:
-        db = torch.empty(cout, device=x.device, dtype=torch.float32)
-    _lib.check(lib.munit_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(),
-                                      _stream()), "conv2d_wgrad")
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample)
+    with _on(x):
+        ws = workspace(pl.ws_wgrad, x.device)
+        if dw is None:
+            dw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32,
+                             memory_format=torch.channels_last)
+            beta = 0.0
+        if db is None and want_bias:
+            db = torch.empty(cout, device=x.device, dtype=torch.float32)
+        _lib.check(lib.munit_conv2d_wgrad(pl.ref, _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(),
+                                          _stream()), "conv2d_wgrad")
+        _count(pl, 2)
     return dw, db
 
 
 def act_bwd_raw(act, slope, y, dy):
     lib = _lib.load()
     dx = torch.empty_like(y)
-    _lib.check(lib.munit_act_bwd(ACT[act], c_float(slope), _p(y), _p(dy), _p(dx), y.numel(), _stream()), "act_bwd")
+    with _on(y):
+        _lib.check(lib.munit_act_bwd(ACT[act], c_float(slope), _p(y), _p(dy), _p(dx), y.numel(), _stream()), "act_bwd")
     return dx
 
 
@@ -205,15 +318,16 @@ def join_side_streams():
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf):
+    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf, owner):
         _require(x, "conv input")
         _require(weight, "conv weight")
         x, w = nhwc(x), nhwc(weight)
-        y = conv2d_fwd_raw(x, w, bias, stride, pad, pad_type, upsample, act, slope)
+        y = conv2d_fwd_raw(x, w, bias, stride, pad, pad_type, upsample, act, slope, owner=owner)
         ctx.cfg = (stride, pad, pad_type, upsample, act, slope)
         ctx.has_bias = bias is not None
         ctx.wbuf = wbuf
         ctx.bbuf = bbuf if bias is not None else None
+        ctx.owner = owner
         ctx.save_for_backward(x, w, y if act != "none" else None)
         return y
 
@@ -239,10 +353,10 @@ class _Conv2d(Function):
                 conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
                                  want_bias=False)
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample)
+            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample, owner=ctx.owner)
         if want_w and ctx.wbuf is None:
             dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def _gbuf(p):
@@ -252,7 +366,8 @@ def _gbuf(p):
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2):
     """pad -> conv -> bias -> activation (networks.py:695-701), optional fused nearest x2
     upsample of the input (networks.py:534)."""
-    return _Conv2d.apply(x, weight, bias, stride, pad, pad_type, upsample, act, slope, _gbuf(weight), _gbuf(bias))
+    return _Conv2d.apply(x, weight, bias, stride, pad, pad_type, upsample, act, slope, _gbuf(weight), _gbuf(bias),
+                         weight)
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -263,12 +378,13 @@ def linear(x, weight, bias=None, act="none"):
     if wbuf is not None:
         wbuf = wbuf.view(n, k, 1, 1)
     y = _Conv2d.apply(x.reshape(b, k, 1, 1), weight.view(n, k, 1, 1), bias, 1, 0, "zero", False, act, 0.2, wbuf,
-                      _gbuf(bias))
+                      _gbuf(bias), weight)
     return y.reshape(b, n)
 
 
 class _InstNorm(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, x, adain, residual, w_off, b_off, relu, eps):
         _require(x, "instance-norm input")
         lib = _lib.load()
@@ -291,9 +407,14 @@ class _InstNorm(Function):
         ctx.cfg = (w_off, b_off, relu, ld)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, stats, adain)
+        if MASK_SINK is not None and relu:
+            if residual is not None:
+                raise RuntimeError("munit_amd: kink recording needs relu and residual on different layers")
+            MASK_SINK.append(y > 0)
         return y
 
     @staticmethod
+    @_guarded
     def backward(ctx, dy):
         lib = _lib.load()
         x, stats, adain = ctx.saved_tensors
@@ -323,6 +444,7 @@ def adain(x, params, w_off, b_off, relu=False, residual=None, eps=1e-5):
 
 class _LayerNorm(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, x, gamma, beta, relu, eps):
         _require(x, "layer-norm input")
         lib = _lib.load()
@@ -337,9 +459,12 @@ class _LayerNorm(Function):
         ctx.gbuf = getattr(gamma, "_munit_grad", None)
         ctx.bbuf = getattr(beta, "_munit_grad", None)
         ctx.save_for_backward(x, stats, gamma, beta)
+        if MASK_SINK is not None and relu:
+            MASK_SINK.append(y > 0)
         return y
 
     @staticmethod
+    @_guarded
     def backward(ctx, dy):
         lib = _lib.load()
         x, stats, gamma, beta = ctx.saved_tensors
@@ -347,16 +472,20 @@ class _LayerNorm(Function):
         dy = nhwc(dy)
         b, c, h, w = x.shape
         dx = torch.empty_like(x)
-        into = ctx.gbuf is not None and ctx.bbuf is not None
+        # accumulate straight into the flat gradient only when autograd actually wants these gradients (a frozen
+        # gamma / beta gets throw-away buffers: the kernel always produces both)
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        into = want and ctx.gbuf is not None and ctx.bbuf is not None
         dgamma = ctx.gbuf if into else torch.empty_like(gamma)
         dbeta = ctx.bbuf if into else torch.empty_like(beta)
         ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
         _lib.check(lib.munit_layernorm_bwd(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(gamma), _p(beta),
                                            _p(dgamma), _p(dbeta), c_float(1.0 if into else 0.0), int(relu),
                                            c_float(eps), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
-        if into:
+        if into or not want:
             return dx, None, None, None, None
-        return dx, dgamma, dbeta, None, None
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None,
+                None)
 
 
 def layer_norm(x, gamma, beta, relu=False, eps=1e-5):
@@ -366,6 +495,7 @@ def layer_norm(x, gamma, beta, relu=False, eps=1e-5):
 
 class _AvgPool3s2(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, x):
         _require(x, "avgpool input")
         lib = _lib.load()
@@ -377,6 +507,7 @@ class _AvgPool3s2(Function):
         return y
 
     @staticmethod
+    @_guarded
     def backward(ctx, dy):
         lib = _lib.load()
         b, c, h, w = ctx.shape
@@ -393,6 +524,7 @@ def avgpool3s2(x):
 
 class _GlobalAvgPool(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, x):
         _require(x, "global-avgpool input")
         lib = _lib.load()
@@ -404,6 +536,7 @@ class _GlobalAvgPool(Function):
         return y
 
     @staticmethod
+    @_guarded
     def backward(ctx, dy):
         lib = _lib.load()
         b, c, h, w = ctx.shape
@@ -420,6 +553,7 @@ def global_avgpool(x):
 
 class _L1Mean(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, a, b, mask):
         _require(a, "l1 input")
         _require(b, "l1 target")
@@ -447,6 +581,7 @@ class _L1Mean(Function):
         return out
 
     @staticmethod
+    @_guarded
     def backward(ctx, gout):
         lib = _lib.load()
         a, b, mask = ctx.saved_tensors
@@ -465,6 +600,7 @@ def l1_mean(a, b, mask=None):
 
 class _MseConst(Function):
     @staticmethod
+    @_guarded
     def forward(ctx, x, target):
         _require(x, "mse input")
         lib = _lib.load()
@@ -478,6 +614,7 @@ class _MseConst(Function):
         return out
 
     @staticmethod
+    @_guarded
     def backward(ctx, gout):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
@@ -516,9 +653,11 @@ def weighted_sum(terms, weights):
     lib = _lib.load()
     n = len(terms)
     out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+    _same_device(*terms)
     ptrs = (c_void_p * n)(*[t.data_ptr() for t in terms])
     ws_ = (c_float * n)(*[float(w) for w in weights])
-    _lib.check(lib.munit_weighted_sum(ptrs, ws_, n, _p(out), _stream()), "weighted_sum")
+    with _on(out):
+        _lib.check(lib.munit_weighted_sum(ptrs, ws_, n, _p(out), _stream()), "weighted_sum")
     return out
 
 
@@ -526,21 +665,26 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     lib = _lib.load()
     for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
         _require(t, "adam " + nm)
-    _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-                                   float(eps), float(weight_decay), int(step), _stream()), "adam_step")
+    _same_device(p, g, m, v)
+    with _on(p):
+        _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                       float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
 def extraadam_step(p, g, m, v, p_saved, lr, beta1, beta2, eps, weight_decay, step, mode):
     lib = _lib.load()
     for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq"), (p_saved, "saved params")):
         _require(t, "extraadam " + nm)
-    _lib.check(lib.munit_extraadam_step(_p(p), _p(g), _p(m), _p(v), _p(p_saved), p.numel(), float(lr), float(beta1),
-                                        float(beta2), float(eps), float(weight_decay), int(step), int(mode),
-                                        _stream()), "extraadam_step")
+    _same_device(p, g, m, v, p_saved)
+    with _on(p):
+        _lib.check(lib.munit_extraadam_step(_p(p), _p(g), _p(m), _p(v), _p(p_saved), p.numel(), float(lr),
+                                            float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                            int(mode), _stream()), "extraadam_step")
 
 
 def scale_(x, alpha):
     lib = _lib.load()
     _require(x, "scale input")
-    _lib.check(lib.munit_scale(_p(x), _p(x), x.numel(), c_float(alpha), 0, _stream()), "scale")
+    with _on(x):
+        _lib.check(lib.munit_scale(_p(x), _p(x), x.numel(), c_float(alpha), 0, _stream()), "scale")
     return x

@@ -41,6 +41,9 @@ class FusedAdam(Optimizer):
         self._step = 0
         self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
         self._views = None
+        # prepared weight images (ops._prepared): items registered on first use, refreshed in one launch per step
+        self._prep_items = []
+        self._prep_table = None
 
     # ---- flat storage -----------------------------------------------------------------
     @staticmethod
@@ -76,9 +79,35 @@ class FusedAdam(Optimizer):
                 gv = self._view(flat_g, off, p)
                 p._munit_grad = gv
                 p.grad = gv
+                p._munit_prep = {}       # the storage moved: every prepared image is void
+                p._munit_opt = self
                 views.append((self._view(flat_m, off, p), self._view(flat_v, off, p)))
         self.flat_p, self.flat_g, self.flat_m, self.flat_v = flat_p, flat_g, flat_m, flat_v
         self._views = views
+        self._prep_items, self._prep_table = [], None
+
+    # ---- prepared weight images ----------------------------------------------------------
+    def register_prepared(self, item):
+        """Called by ops._prepared the first time a layer needs a re-laid-out image of one of this optimizer's
+        weights (backward-data transpose, sub-pixel phase merge)."""
+        self._prep_items.append(item)
+        self._prep_table = None
+
+    def refresh_prepared(self):
+        """Rebuild every registered image from the current weights: one kernel launch on the current stream.
+        The reference re-derives nothing here (cuDNN transposes inside its kernels); this build re-laid each
+        weight 4-6 times per step inside the conv calls before (452 launches), now once."""
+        n = len(self._prep_items)
+        if n == 0 or not self.flat_p.is_cuda:
+            return
+        if self._prep_table is None:
+            import ctypes
+            from ._lib import PrepItem
+            arr = (PrepItem * n)(*self._prep_items)
+            host = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))),
+                                    dtype=torch.uint8)
+            self._prep_table = host.to(self.flat_p.device)
+        ops.prepare_weights_batch(self._prep_table, n)
 
     # ---- optimizer API ----------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -90,6 +119,7 @@ class FusedAdam(Optimizer):
         self._step += 1
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
                       g["eps"], g["weight_decay"], self._step)
+        self.refresh_prepared()
 
     def state_dict(self):
         state = {}
@@ -140,6 +170,7 @@ class FusedExtraAdam(FusedAdam):
         self._step += 1
         ops.extraadam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_saved, g["lr"],
                            g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step, mode)
+        self.refresh_prepared()
 
     @torch.no_grad()
     def extrapolation(self):
@@ -154,6 +185,7 @@ class FusedExtraAdam(FusedAdam):
         self._has_copy = False
 
 
+FORCE_ALLREDUCE = bool(os.environ.get("MUNIT_FORCE_ALLREDUCE"))
 BRANCH_STREAMS = not os.environ.get("MUNIT_NO_BRANCH_STREAMS")   # bench.py clears it while it times single kernels
 
 
@@ -356,14 +388,19 @@ class MUNIT_Trainer(nn.Module):
 
     @staticmethod
     def _all_reduce_mean(flat):
-        """Data-parallel exchange: one all-reduce (RCCL over xGMI) of the flat gradient."""
+        """Data-parallel exchange: one all-reduce (RCCL over xGMI) of the flat gradient.  MUNIT_FORCE_ALLREDUCE=1
+        issues it at world size 1 too (a 1-GPU box then exercises the RCCL path; the result is unchanged)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size()
+        if world > 1 or FORCE_ALLREDUCE:
             dist.all_reduce(flat)
-            if flat.is_cuda:
-                ops.scale_(flat, 1.0 / dist.get_world_size())
-            else:
-                flat.mul_(1.0 / dist.get_world_size())
+            if world > 1:
+                if flat.is_cuda:
+                    ops.scale_(flat, 1.0 / world)
+                else:
+                    flat.mul_(1.0 / world)
 
     # ---- gen_update (trainer.py:336-561) -----------------------------------------------
     def gen_update(self, x_a, x_b, hyperparameters, mask_a=None, mask_b=None, comet_exp=None, synth=False,

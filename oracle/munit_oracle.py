@@ -41,8 +41,35 @@ LN_EPS = 1e-5  # LayerNorm default (networks.py:852)
 # --------------------------------------------------------------------------------------
 # primitive ops
 # --------------------------------------------------------------------------------------
+class KinkMasks:
+    """Optional test hook (tests/parity.py): sign patterns of every ReLU / LeakyReLU, in call order, recorded from
+    another run of the same network.  While one is installed in KINK_MASKS, `activation` takes the recorded branch
+    instead of its own comparison, so two runs that differ only by rounding differentiate the SAME piecewise-linear
+    function (a pre-activation within rounding noise of 0 otherwise switches an upstream gradient element on or
+    off).  Values change by at most that noise; the default (None) is the plain activation."""
+
+    def __init__(self, masks):
+        self.masks, self.pos = list(masks), 0
+
+    def take(self, x: Tensor) -> Tensor:
+        assert self.pos < len(self.masks), "more activations than recorded masks"
+        m = self.masks[self.pos]
+        self.pos += 1
+        assert m.numel() == x.numel() and m.shape[0] == x.shape[0], (self.pos, tuple(m.shape), tuple(x.shape))
+        return m.reshape(x.shape)
+
+    def done(self) -> bool:
+        return self.pos == len(self.masks)
+
+
+KINK_MASKS: Optional[KinkMasks] = None
+
+
 def activation(x: Tensor, kind: str) -> Tensor:
     """networks.py:668-681 (relu / lrelu 0.2 / tanh / none)."""
+    if KINK_MASKS is not None and kind in ("relu", "lrelu"):
+        m = KINK_MASKS.take(x)
+        return torch.where(m, x, x * (0.0 if kind == "relu" else 0.2))
     if kind == "relu":
         return torch.clamp_min(x, 0)
     if kind == "lrelu":
@@ -151,7 +178,7 @@ def mlp(sd: State, pre: str, style: Tensor, n_blk: int = 3) -> Tensor:
     for i in range(n_blk):
         h = F.linear(h, sd[pre + "model.%d.fc.weight" % i], sd[pre + "model.%d.fc.bias" % i])
         if i < n_blk - 1:
-            h = torch.clamp_min(h, 0)
+            h = activation(h, "relu")
     return h
 
 

@@ -26,26 +26,27 @@ def l2err(a, ref):
 
 
 class GradCheck:
-    """Gradient tolerance of one iteration vs the fp64 oracle.  SURVEY.md section 8c proposes 1e-2
-    normalised max error.  The kernels themselves are pinned much tighter (1e-4) by the op-level
-    tests on identical inputs; at step level one more effect exists, measured on the box with
-    tools/diag_grad.py and tools/diag_xab.py: a ReLU pre-activation within fp32 noise of 0 takes the
-    other branch than in fp64, which switches ONE element of an upstream gradient on or off.
-      * In a 16x16x256 resblock map it shows up as an isolated error of a few 1e-2 of max|g| in one
-        output-channel row of a weight gradient.
-      * In the last style-encoder layer (4x4x256 at the 64x64 test size) one flipped element is
-        1/4096 of the style gradient's energy, i.e. ~1.6e-2 relative L2, spread smoothly over its 46x46
-        receptive field of x_ab -- and therefore over every tensor upstream of x_ab (measured:
-        swapping only the summation order of the image-head conv, 1e-6 in x_ab, moves 40 % of the
-        tensors by 2.5e-2 while x_ba's side stays at 5e-4).
-    Which elements flip changes with any reordering of a sum, in any fp32 implementation (torch's
-    CPU fp32 run shows the same signature).  So the step-level rule is: every tensor within 5e-2
-    relative L2 and 1e-1 normalised max (wiring / accumulation / loss-weight errors are O(1)), and
-    the MEDIAN tensor within 2e-3 relative L2 (torch-CPU fp32 vs fp64 measures 4e-4..1.5e-3)."""
+    """Gradient tolerance of one iteration vs the fp64 oracle: SURVEY.md section 8c's 1e-2 normalised max error on
+    EVERY tensor, with the kinks pinned.
 
-    L2_MEDIAN, L2_HARD, MAX_HARD = 2e-3, 5e-2, 1e-1
+    Why pinning: the network is piecewise linear in ~10^6 places (ReLU / LeakyReLU).  A pre-activation within fp32
+    rounding noise of 0 takes the other branch in fp64, which switches one element of an upstream gradient on or off;
+    in the last style-encoder layer (4x4x256 at the 64x64 test size) a single flip is ~1.6e-2 relative L2 of every
+    tensor upstream of x_ab (measured in round 1, tools/diag_grad.py / diag_xab.py; torch's own CPU fp32 run against
+    fp64 shows the same signature).  That is a property of comparing two roundings of a non-smooth function, not of
+    the kernels, and it used to be absorbed by a 5e-2 / 1e-1 per-tensor bound.  Now the HIP forward records the sign
+    pattern behind every ReLU / LeakyReLU (ops.MASK_SINK) and the fp64 oracle takes the same branches
+    (oracle.KINK_MASKS), so both sides differentiate the same piecewise-linear function and the comparison is tight:
+        pinned:    every tensor <= 1e-2 normalised max AND <= 1e-2 relative L2, median L2 <= 1e-3
+        unpinned:  (diagnostic mode, pin_kinks=False) every tensor <= 5e-2 L2 / 1e-1 max, median <= 2e-3, and at
+                   most 10 % of the tensors looser than 1e-2 max -- listed by name in the report."""
 
-    def __init__(self):
+    def __init__(self, pinned=True):
+        self.pinned = pinned
+        if pinned:
+            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 1e-3, 1e-2, 1e-2
+        else:
+            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 2e-3, 5e-2, 1e-1
         self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0
         self.kinks = self.loose
 
@@ -56,12 +57,16 @@ class GradCheck:
         if e > 1e-2 or l2 > 5e-3:
             self.loose.append((name, round(e, 5), round(l2, 5)))
         if check:
-            assert l2 <= self.L2_HARD and e <= self.MAX_HARD, ("grad", name, e, l2)
+            assert l2 <= self.L2_HARD and e <= self.MAX_HARD, ("grad", name, e, l2, "pinned" if self.pinned else "unpinned")
 
     def finish(self, check=True):
         self.median = sorted(self.l2s)[len(self.l2s) // 2] if self.l2s else 0.0
         if check:
             assert self.median <= self.L2_MEDIAN, ("median grad l2", self.median, self.loose)
+            if not self.pinned:
+                assert len(self.loose) <= max(1, len(self.l2s) // 10), ("too many loose tensors", self.loose)
+
+
 
 
 def oracle_states(hp, dtype):
@@ -109,15 +114,18 @@ def trainer_named_params(trainer):
 
 
 def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", oracle_dtype=torch.float64,
-                    step_size=2, check=True, optimizer="adam", precision=None):
+                    step_size=2, check=True, optimizer="adam", precision=None, guided=1, recon_mask=1, pin_kinks=True):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
     losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end)."""
+    from munit_amd import ops
     from munit_amd.trainer import MUNIT_Trainer
 
     hp = O.default_hp(size, batch, gen_state)
     hp["step_size"] = step_size
     hp["optimizer"] = optimizer
+    hp["guided"] = guided            # 0: translate with sampled styles (trainer.py:377-379, 1155-1157)
+    hp["recon_mask"] = recon_mask    # 0: unmasked cycle reconstruction (trainer.py:438-440)
     if precision is not None:
         hp["precision"] = precision      # build extension: compute mode of the HIP trainer (the oracle ignores it)
     gen, dis_a, dis_b = oracle_states(hp, oracle_dtype)
@@ -143,14 +151,42 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
             with torch.no_grad():
                 for (n, p), q in list(zip(gnames, o_gen)) + list(zip(dnames, o_dis)):
                     q.copy_(p.detach().to(oracle_dtype).cpu())
-        gc = GradCheck()
+        gc = GradCheck(pinned=pin_kinks)
         tr.iterations = orc.iterations = it  # train.py:157,328: the caller owns the counter
         tr.update_learning_rate()
         orc.update_learning_rate()
         assert abs(tr.gen_opt.param_groups[0]["lr"] - orc._lr()) < 1e-15
         before = [p.detach().double().cpu().clone() for _, p in gnames + dnames]
-        tr.dis_update(dx_a, dx_b, hp)
-        d_ref = orc.dis_update(ox[0], ox[1])
+        # the reference draws s_a, s_b from the host RNG inside each update (trainer.py:366-367, 1146-1147); replay the
+        # same stream for the oracle (only guided == 0 consumes them)
+        def styles(seed):
+            torch.manual_seed(seed)
+            return (torch.randn(batch, hp["gen"]["style_dim"], 1, 1).to(oracle_dtype),
+                    torch.randn(batch, hp["gen"]["style_dim"], 1, 1).to(oracle_dtype))
+
+        def hip(fn, seed):
+            """run one HIP update with the host RNG at `seed`, recording the ReLU / LeakyReLU sign patterns"""
+            torch.manual_seed(seed)
+            ops.MASK_SINK = [] if pin_kinks else None
+            try:
+                fn()
+                masks = ops.MASK_SINK
+            finally:
+                ops.MASK_SINK = None
+            return O.KinkMasks([m.cpu() for m in masks]) if pin_kinks else None
+
+        def oracle(fn, masks):
+            O.KINK_MASKS = masks
+            try:
+                out = fn()
+                assert masks is None or masks.done(), "the oracle ran fewer activations than the HIP forward recorded"
+            finally:
+                O.KINK_MASKS = None
+            return out
+
+        km = hip(lambda: tr.dis_update(dx_a, dx_b, hp), 100 + it)
+        sa, sb = styles(100 + it)
+        d_ref = oracle(lambda: orc.dis_update(ox[0], ox[1], sa, sb), km)
         for (n, p), g in zip(dnames, d_ref):
             gc.add("dis." + n, p._munit_grad, g, check)
         # D just took an Adam step on both sides; its sign-like noise (see below) would otherwise leak
@@ -161,8 +197,10 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         with torch.no_grad():
             for (n, p), q in zip(dnames, o_dis):
                 q.copy_(p.detach().to(oracle_dtype).cpu())
-        tr.gen_update(dx_a, dx_b, hp, dm_a, dm_b)
-        g_ref = orc.gen_update(ox[0], ox[1], ox[2], ox[3])
+        km = hip(lambda: tr.gen_update(dx_a, dx_b, hp, dm_a if recon_mask else None, dm_b if recon_mask else None),
+                 200 + it)
+        sa, sb = styles(200 + it)
+        g_ref = oracle(lambda: orc.gen_update(ox[0], ox[1], ox[2], ox[3], sa, sb), km)
         for (n, p), g in zip(gnames, g_ref):
             if g is None:
                 continue
@@ -202,7 +240,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
                 rep["weight_abs"] = max(rep.get("weight_abs", 0.0), float((a - r).abs().max()))
                 rep["weight_l2"] = max(rep.get("weight_l2", 0.0), float((a - r).norm() / r.norm().clamp_min(1e-30)))
         if check:
-            assert rep["moment_l2"] <= 2 * GradCheck.L2_HARD, rep["moment_l2"]
+            assert rep["moment_l2"] <= 2 * gc.L2_HARD, rep["moment_l2"]
             assert rep["weight_abs"] <= 4.0 * hp["lr"], rep["weight_abs"]
             assert rep["weight_l2"] <= 2e-3, rep["weight_l2"]
     rep["weight_nerr"] = rep["weight_abs"]

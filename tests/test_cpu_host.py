@@ -209,6 +209,25 @@ def test_data_parallel_exchange_gloo_world2(tmp_path):
         assert p.returncode == 0, o
 
 
+def test_bench_self_launches_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` without a launcher must start the two ranks itself (children of a GPU-free parent),
+    relay rank 0's single JSON line and return 0; --dry-run keeps it on the CPU (gloo rendezvous + all-reduce)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=ROOT, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2"
+    # a launcher / --gpus mismatch is refused instead of silently running another world size
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=ROOT, env=env2, timeout=600)
+    assert p.returncode != 0 and b"does not match" in p.stderr
+
+
 def test_compute_mode_plumbing_without_gpu():
     """munit_conv_desc.compute / ops.set_compute: names, values and validation (no kernel is launched)."""
     import ctypes

@@ -71,3 +71,78 @@ def test_two_rank_step_matches_single_process_on_the_joint_batch(tmp_path):
     # mean over ranks of per-rank batch means == mean over the joint batch (fp32 summation order differs)
     assert l2err(r0["g_dis"], g_dis.double()) <= 1e-4, l2err(r0["g_dis"], g_dis.double())
     assert l2err(r0["g_gen"], g_gen.double()) <= 2e-3, l2err(r0["g_gen"], g_gen.double())
+
+
+_NCCL_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+os.environ["MUNIT_FORCE_ALLREDUCE"] = "1"
+import bench
+from munit_amd import trainer as T
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+hp = bench.bench_hp(64, 2)
+batch = tuple(t.to(dev) for t in bench.make_batch(2, 64, 0))
+
+def run():
+    torch.manual_seed(1234)
+    tr = T.MUNIT_Trainer(hp); tr.to(dev)
+    torch.manual_seed(11)
+    tr.update_learning_rate(); tr.dis_update(batch[0], batch[1], hp); tr.gen_update(batch[0], batch[1], hp, batch[2], batch[3])
+    torch.cuda.synchronize()
+    return tr
+
+ref = run()                                      # no process group yet: no exchange
+dist.init_process_group("nccl", init_method="file://" + %(rdzv)r, rank=0, world_size=1, device_id=dev)
+assert T.FORCE_ALLREDUCE
+got = run()                                      # same step with the RCCL all-reduce of both flat gradients issued
+for a, b in zip(ref.parameters(), got.parameters()):
+    assert torch.equal(a, b)
+# and the exchange on its own: 109 MB flat generator gradient, device events on the stream RCCL is enqueued from
+g = got.gen_opt.flat_g
+before = g.clone()
+for _ in range(3):
+    dist.all_reduce(g)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    dist.all_reduce(g)
+e1.record()
+torch.cuda.synchronize()
+assert torch.equal(g, before)                    # world size 1: SUM over one rank
+print(json.dumps({"nccl_world1_allreduce_ms": e0.elapsed_time(e1) / 10, "mbytes": g.numel() * 4 / 1e6}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_nccl_backend_world1_step(tmp_path):
+    """The RCCL branch of the data-parallel path, executed once on the one GPU of the box: init_process_group("nccl"),
+    all_reduce of both flat gradient buffers inside dis_update / gen_update (MUNIT_FORCE_ALLREDUCE=1), destroy.  With
+    one rank the exchange must leave every weight bit-identical to the step without a process group."""
+    import subprocess
+    script = tmp_path / "nccl_w.py"
+    script.write_text(_NCCL_WORKER % dict(root=ROOT, rdzv=str(tmp_path / "rdzv")))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT, env=env,
+                       timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    print(out.strip().splitlines()[-1])
+
+
+def test_bench_under_torchrun_one_rank():
+    """The driver's launch form (python -m torch.distributed.run ... bench.py --gpus N) with N = 1: the nccl group,
+    the barriers around the timed region and the MAX all-reduce of the elapsed time all execute."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MUNIT_FORCE_ALLREDUCE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--size", "64", "--batch", "2", "--no-cpu-baseline", "--no-roofline", "--no-modes"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"

@@ -1,7 +1,9 @@
 """Summarise the three rocprofv3 --pmc passes of bench.py into profiles/<tag>_pmc_hbm_mfma.txt.
   python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <mfma_counter_collection.csv> <out.txt>
 FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md); KB -> MB per launch."""
-import collections, csv, re, sys
+import collections, csv, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # lib_fingerprint(): ties this summary to the kernel sources it was collected on (bench.py checks it)
 
 
 def load(path, name):
@@ -21,7 +23,8 @@ f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
 m = load(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES")
 g = load(sys.argv[3], "GRBM_GUI_ACTIVE")
-out = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (three separate passes) of",
+out = ["# kernel-source fingerprint: " + bench.lib_fingerprint(),
+       "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (three separate passes) of",
        "`MUNIT_NO_SIDE_STREAM=1 MUNIT_NO_BRANCH_STREAMS=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline`, MI355X",
        "FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); KB -> MB, per launch.",
        "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCD * 1024 SIMD); clock (MHz) = GRBM_GUI_ACTIVE / 8 / duration.",

@@ -51,6 +51,7 @@ struct IgemmParams {
   int ksplit, kt_per_split;
   float* slab;
   int ct;    // compute type (aligned variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3 split
+  int patch; // ROLE 2: at most two padded positions per axis fold onto a pixel -> direct-to-LDS tiles + LDS patch
 };
 
 // row index -> (sample, output row, output column)
@@ -146,7 +147,15 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // fetches global chunk p ^ ((r >> 1) & 7), and the fragment reads undo it.
   constexpr bool BF16 = CT == 1 || CT == 2;
   constexpr bool DMA = CT == 3;
-  static_assert(!DMA || (ROLE != 2 && ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned single-gather variants only");
+  static_assert(!DMA || (ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned variants only");
+  // ROLE 2 with CT == 3 ("fold by LDS patch"): layers whose pad adjoint folds at most two padded positions per axis onto
+  // a source pixel (no up-sampling; reflect pad 1 of the 3x3 resblock convs).  The primary position of every row is a
+  // direct-to-LDS load like any forward tile; the up to three further combinations (column partner, row partner, both)
+  // are fetched into registers next to it and added to the wave's OWN landed rows after s_waitcnt vmcnt(0), before the
+  // barrier that publishes the tile.  Exact (the GEMM is linear in A); only waves that hold a border pixel take the
+  // branch, and no load depends on another (the register-path variant pays a dependent round trip per K-tile in the
+  // blocks that hold a corner pixel).
+  constexpr bool PATCH = DMA && ROLE == 2;
   constexpr int NPL = CT == 2 ? 3 : 1;     // bf16 planes per operand
   static_assert(!BF16 || ALIGNED, "bf16 operands need Cin % 32 == 0");
   // 8 waves per block: four waves per SIMD with two blocks per CU keep the matrix pipe fed while other
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   bool a_ok[AROWS];
   uint2 a_ch[AROWS], a_cw[AROWS];  // ROLE 2 only: packed fold candidates per axis
   int a_nc[AROWS];                 // ROLE 2 only: candidate counts (rows | cols << 4)
+  int f_h1[PATCH ? AROWS : 1], f_w1[PATCH ? AROWS : 1];   // PATCH: second padded position per axis minus (K-1), or a sentinel
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     int m = m0 + r0 + RSTEP * i;
@@ -216,7 +226,23 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
     a_base[i] = b * p.H * p.W;
     a_ih0[i] = oh * p.stride - p.pad;
     a_iw0[i] = ow * p.stride - p.pad;
-    if constexpr (ROLE == 2) {
+    if constexpr (PATCH) {
+      // padded positions folding onto (oh, ow): oh + P always; with reflect padding the mirror image of rows 1..P and
+      // Hu-1-P..Hu-2 as well (the host admits this variant only when at most one of the two applies)
+      constexpr int NONE = -(1 << 20);
+      const int P = p.f_pad, K1 = p.KH - 1;
+      int h1 = NONE, w1 = NONE;
+      if (p.f_reflect) {
+        if (oh >= 1 && oh <= P) h1 = P - oh - K1;
+        else if (oh >= p.f_Hu - 1 - P && oh <= p.f_Hu - 2) h1 = 2 * p.f_Hu - 2 - oh + P - K1;
+        if (ow >= 1 && ow <= P) w1 = P - ow - K1;
+        else if (ow >= p.f_Wu - 1 - P && ow <= p.f_Wu - 2) w1 = 2 * p.f_Wu - 2 - ow + P - K1;
+      }
+      a_ih0[i] = oh + P - K1;
+      a_iw0[i] = ow + P - K1;
+      f_h1[i] = h1;
+      f_w1[i] = w1;
+    } else if constexpr (ROLE == 2) {
       a_ch[i] = fold_cands(oh, p.f_Hu, p.f_ups, p.f_pad, p.f_reflect);
       a_cw[i] = fold_cands(ow, p.f_Wu, p.f_ups, p.f_pad, p.f_reflect);
       int nh = 0, nw = 0;
@@ -246,11 +272,21 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // (-1 = contributes zero); recomputed only when the tap changes, i.e. every Cin/32 K-tiles
   int aoff[AROWS];
   int aoff1[ROLE == 2 ? AROWS : 1];
+  int aoffp[PATCH ? 3 : 1][AROWS];   // PATCH: (h0,w1), (h1,w0), (h1,w1)
+  f32x4 xp[PATCH ? 3 : 1][AROWS];    // PATCH: their values for the tile in flight
 
   auto tap_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      if constexpr (ROLE == 2) {
+      if constexpr (PATCH) {
+        const int vh0 = a_ih0[i] + kh, vh1 = f_h1[i] + kh, vw0 = a_iw0[i] + kw, vw1 = f_w1[i] + kw;
+        const bool h0 = a_ok[i] && (unsigned)vh0 < (unsigned)p.H, h1 = a_ok[i] && (unsigned)vh1 < (unsigned)p.H;
+        const bool w0 = (unsigned)vw0 < (unsigned)p.W, w1 = (unsigned)vw1 < (unsigned)p.W;
+        aoff[i] = (h0 && w0) ? (a_base[i] + vh0 * p.W + vw0) * p.Cin : -1;
+        aoffp[0][i] = (h0 && w1) ? (a_base[i] + vh0 * p.W + vw1) * p.Cin : -1;
+        aoffp[1][i] = (h1 && w0) ? (a_base[i] + vh1 * p.W + vw0) * p.Cin : -1;
+        aoffp[2][i] = (h1 && w1) ? (a_base[i] + vh1 * p.W + vw1) * p.Cin : -1;
+      } else if constexpr (ROLE == 2) {
         const int nw = a_nc[i] >> 4;
         const int ncomb = (a_nc[i] & 15) * nw;
         int o0 = -1, o1 = -1;
@@ -385,6 +421,14 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
         float* l = smem + buf * (BM * 32) + (wrow + RSTEP * i) * 32;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        if constexpr (PATCH) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (aoffp[c][i] >= 0) v = *reinterpret_cast<const f32x4*>(xg + (long long)aoffp[c][i] + c0 + dma_col);
+            xp[c][i] = v;
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
@@ -540,9 +584,23 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // passed the barrier that ended tile t-1 and nobody reads that buffer before the next barrier -- and the
   // loads of tile t+2 are issued into the freed registers.  One barrier per K-tile.
   const int nk = kt_end - kt_begin;
+  // PATCH: add the partner combinations to this lane's own landing spot (row r0 + RSTEP*i, position c4) of buffer buf;
+  // called after s_waitcnt vmcnt(0), i.e. once the wave's own direct-to-LDS rows and the partner registers have arrived
+  auto patch_tile = [&](int buf) {
+    if constexpr (PATCH) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        if ((aoffp[0][i] & aoffp[1][i] & aoffp[2][i]) >= 0) {   // any of the three offsets is valid (-1 = none)
+          f32x4* l = reinterpret_cast<f32x4*>(smem + buf * (BM * 32) + (r0 + RSTEP * i) * 32 + c4 * 4);
+          *l = *l + ((xp[0][i] + xp[1][i]) + xp[2][i]);
+        }
+      }
+    }
+  };
   if constexpr (DMA) {
     if (nk > 0) dma_tile(kt_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 0) patch_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
@@ -550,6 +608,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
       compute_half(cur, 0);
       compute_half(cur, 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kt + 1 < nk) patch_tile(cur ^ 1);
       __syncthreads();
     }
   } else if constexpr (CT == 2) {
@@ -872,7 +931,10 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
       munit_set_error("conv_igemm: folded backward-data needs Cout %% 32 == 0");
       return MUNIT_ERR_ARG;
     }
-    if (bn == 64) {
+    if (p.ct == 0 && p.patch && !p.frame && NWAVES == 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_PATCH")) {
+      if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, 3>), grid, block, 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_kernel<128, true, 2, 3>), grid, block, 0, st, q);
+    } else if (bn == 64) {
       if (p.ct == 2) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, 2>), grid, block, 0, st, q);
       else if (p.ct == 1) hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2, 1>), grid, block, 0, st, q);
       else hipLaunchKernelGGL((conv_igemm_kernel<64, true, 2>), grid, block, 0, st, q);
@@ -1181,6 +1243,8 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
+    p.patch = d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, p.f_reflect) <= 2 &&
+              max_fold_cands(d->W, 0, d->pad, p.f_reflect) <= 2;
     if (pl.boxsum) {
       // interior source pixels 2..H-3 x 2..W-3: dx[i][j] = sum_taps wt[t][r] . S[2i-2+t][2j-2+r] -- one gather per element
       {

@@ -42,6 +42,12 @@ CONV_CASES = [
     (32, 48, 3, 1, 1, "zero", 0, "relu", 2, 9, 11),         # zero pad, odd sizes, odd channels
     (36, 20, 4, 2, 1, "reflect", 0, "none", 2, 9, 11),      # unaligned Cin, odd sizes with stride 2
     (64, 64, 4, 2, 1, "reflect", 0, "none", 2, 2, 2),       # tiniest reflect case (2x2 -> 1x1)
+    # stride-1 reflect layers whose backward-data folds <= 2 padded positions per axis: direct-to-LDS tiles + LDS patch
+    (256, 256, 3, 1, 1, "reflect", 0, "none", 2, 20, 24),   # several M-tiles, rows that straddle tile boundaries
+    (64, 96, 3, 1, 1, "reflect", 0, "relu", 1, 4, 5),       # smallest extent with at most one mirror per row (H = 4)
+    (64, 64, 5, 1, 2, "reflect", 0, "none", 2, 7, 9),       # pad 2: two mirrored rows per edge
+    (32, 64, 7, 1, 3, "reflect", 0, "none", 1, 10, 13),     # pad 3
+    (64, 64, 3, 1, 1, "reflect", 0, "none", 1, 3, 3),       # H = 3: row 1 mirrors both ways -> register-path fallback
 ]
 
 

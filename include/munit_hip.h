@@ -47,6 +47,11 @@ enum { MUNIT_COMPUTE_F32 = 0, MUNIT_COMPUTE_BF16 = 1, MUNIT_COMPUTE_F32X3 = 2 };
 int munit_version(void);
 const char* munit_last_error(void);
 
+/* Stream plumbing (no reference counterpart: torch's autograd engine orders everything on one stream).  `waiter` waits
+ * for all work enqueued so far on `signaler`; both streams belong to the current device.  Used to fork backward-weight
+ * onto a side stream without creating torch Event / Stream objects per layer. */
+int munit_stream_wait_stream(munit_stream_t waiter, munit_stream_t signaler);
+
 /* ------------------------------------------------------------------------------------
  * Convolution.  Replaces nn.ReflectionPad2d/ZeroPad2d + nn.Conv2d (+ bias + activation)
  * of Conv2dBlock.forward (scripts/networks.py:695-701, pads :642-649, conv :691-693),

@@ -62,8 +62,13 @@ def _require(t, name="tensor"):
         raise RuntimeError("munit_amd: %s must be float32, got %s" % (name, t.dtype))
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream     # (device index) -> hipStream_t as int; no Stream object per call
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Current stream of the current device (every launch sits inside _on(tensor), so that is the tensor's device)."""
+    return c_void_p(_raw_stream(_cur_device()))
 
 
 def _p(t):
@@ -92,13 +97,18 @@ def empty_nhwc(b, c, h, w, like):
     return torch.empty((b, c, h, w), device=like.device, dtype=torch.float32, memory_format=torch.channels_last)
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream it is used on."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+def workspace(nbytes, device, stream=None):
+    """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream it is used on (`stream`: a
+    torch.cuda.Stream other than the current one, e.g. the backward-weight side stream)."""
+    key = (device.index, _raw_stream(device.index) if stream is None else stream.cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes * 1.25), 1 << 20)
-        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        if stream is None:
+            buf = torch.empty(size, dtype=torch.uint8, device=device)
+        else:
+            with torch.cuda.stream(stream):      # the block must belong to the stream that uses it (allocator reuse rule)
+                buf = torch.empty(size, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
@@ -141,10 +151,27 @@ def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none
     return pl
 
 
+class _Here(object):
+    """no-op context: the tensor already lives on the current device (the common case, kept off the slow path)"""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
 def _on(t):
     """Context for launching on t's device: kernels and streams are per device, the process-wide current device may
     be another one (trainer on cuda:N without torch.cuda.set_device(N))."""
-    return torch.cuda.device_of(t)
+    idx = t.device.index
+    if idx is None or idx == _cur_device():
+        return _HERE
+    return torch.cuda.device(idx)
 
 
 def _same_device(*ts):
@@ -161,7 +188,10 @@ def _same_device(*ts):
 def _guarded(fn):
     """Run a Function.forward / backward on the device of its first tensor argument (see _on)."""
     def wrapper(ctx, t, *args):
-        with torch.cuda.device_of(t):
+        idx = t.device.index
+        if idx is None or idx == _cur_device():
+            return fn(ctx, t, *args)
+        with torch.cuda.device(idx):
             return fn(ctx, t, *args)
     return wrapper
 
@@ -260,8 +290,9 @@ def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=N
 
 
 def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=None, db=None, beta=0.0,
-                     want_bias=True):
-    """dw/db given -> accumulate (beta) in place; else fresh tensors are returned."""
+                     want_bias=True, stream=None):
+    """dw/db given -> accumulate (beta) in place; else fresh tensors are returned.  `stream`: launch on this
+    torch.cuda.Stream instead of the current one (dw / db must then be given: nothing is allocated for another stream)."""
     lib = _lib.load()
     x, dy = nhwc(x), nhwc(dy)
     _same_device(x, dy, dw, db)
@@ -269,15 +300,18 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
     cout, _, kh, kw = weight_shape
     pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample)
     with _on(x):
-        ws = workspace(pl.ws_wgrad, x.device)
+        ws = workspace(pl.ws_wgrad, x.device, stream)
         if dw is None:
+            assert stream is None
             dw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32,
                              memory_format=torch.channels_last)
             beta = 0.0
         if db is None and want_bias:
+            assert stream is None
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
-        _lib.check(lib.munit_conv2d_wgrad(pl.ref, _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(),
-                                          _stream()), "conv2d_wgrad")
+        st = _stream() if stream is None else c_void_p(stream.cuda_stream)
+        _lib.check(lib.munit_conv2d_wgrad(pl.ref, _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(), st),
+                   "conv2d_wgrad")
         _count(pl, 2)
     return dw, db
 
@@ -342,11 +376,12 @@ class _Conv2d(Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if want_w and ctx.wbuf is not None:
             if SIDE_STREAM_WGRAD:
-                main, side = torch.cuda.current_stream(dy.device), _side_stream(dy.device)
-                side.wait_stream(main)          # dy, x and the zeroed gradient buffer are ready on main
-                with torch.cuda.stream(side):
-                    conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf,
-                                     beta=1.0, want_bias=False)
+                side = _side_stream(dy.device)
+                with _on(dy):                   # dy, x and the zeroed gradient buffer are ready on the current stream
+                    _lib.check(_lib.load().munit_stream_wait_stream(c_void_p(side.cuda_stream), _stream()),
+                               "stream_wait_stream")
+                conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
+                                 want_bias=False, stream=side)
                 x.record_stream(side)
                 dy.record_stream(side)
             else:

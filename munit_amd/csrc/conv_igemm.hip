@@ -274,6 +274,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   int aoff1[ROLE == 2 ? AROWS : 1];
   int aoffp[PATCH ? 3 : 1][AROWS];   // PATCH: (h0,w1), (h1,w0), (h1,w1)
   f32x4 xp[PATCH ? 3 : 1][AROWS];    // PATCH: their values for the tile in flight
+  bool wave_patch = false;           // PATCH: some lane of this wave has a partner at the current tap (wave-uniform)
 
   auto tap_setup = [&]() {
 #pragma unroll
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
         aoffp[0][i] = (h0 && w1) ? (a_base[i] + vh0 * p.W + vw1) * p.Cin : -1;
         aoffp[1][i] = (h1 && w0) ? (a_base[i] + vh1 * p.W + vw0) * p.Cin : -1;
         aoffp[2][i] = (h1 && w1) ? (a_base[i] + vh1 * p.W + vw1) * p.Cin : -1;
+        if (i == 0) wave_patch = false;
+        wave_patch = wave_patch || __builtin_amdgcn_ballot_w64((aoffp[0][i] & aoffp[1][i] & aoffp[2][i]) >= 0) != 0;
       } else if constexpr (ROLE == 2) {
         const int nw = a_nc[i] >> 4;
         const int ncomb = (a_nc[i] & 15) * nw;
@@ -422,11 +425,13 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         if constexpr (PATCH) {
+          if (wave_patch) {   // scalar branch: interior waves issue nothing here
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (aoffp[c][i] >= 0) v = *reinterpret_cast<const f32x4*>(xg + (long long)aoffp[c][i] + c0 + dma_col);
-            xp[c][i] = v;
+            for (int c = 0; c < 3; ++c) {
+              f32x4 v = {0.f, 0.f, 0.f, 0.f};
+              if (aoffp[c][i] >= 0) v = *reinterpret_cast<const f32x4*>(xg + (long long)aoffp[c][i] + c0 + dma_col);
+              xp[c][i] = v;
+            }
           }
         }
       }
@@ -588,6 +593,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // called after s_waitcnt vmcnt(0), i.e. once the wave's own direct-to-LDS rows and the partner registers have arrived
   auto patch_tile = [&](int buf) {
     if constexpr (PATCH) {
+      if (!wave_patch) return;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         if ((aoffp[0][i] & aoffp[1][i] & aoffp[2][i]) >= 0) {   // any of the three offsets is valid (-1 = none)

@@ -34,6 +34,10 @@ struct WgradParams {
   int ct;                      // compute type (FAST variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3
 };
 
+// 16 bytes of zeros: rows past the end of a split / taps in zero padding are pointed here by the direct-to-LDS loader
+__device__ const float munit_wgrad_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+constexpr int DMA_MAX_HW = 1024;   // Ho + Wo entries of the direct-to-LDS loader's offset tables
+
 // row index -> (sample, output row, output column); same enumeration as conv_igemm.hip
 __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, int& oh, int& ow) {
   if (!frame) {
@@ -106,9 +110,15 @@ __device__ inline int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (
 
 // CT: 0 fp32 MFMA, 1 bf16 operands, 2 f32x3 (three exact bf16 planes per operand, six product terms; see
 // conv_igemm.hip).  f32x3 keeps one LDS buffer of 3 planes (two barriers per step).
+// CT == 3 (fp32, FAST conditions, Cin % WKT == 0 so that one filter tap serves the whole k-tile of a block): the tiles
+// travel global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write), and the gathered source offset
+// of an output pixel is rowoff[oh] + coloff[ow] from two small LDS tables built once per block (the reflect / zero-pad /
+// upsample coordinate map of that tap) instead of ~45 VALU instructions per row and step.
 template <int BC, bool ALIGNED, bool FAST, int CT = 0>
 __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
-  constexpr bool BF16 = CT != 0;
+  constexpr bool DMA = CT == 3;
+  constexpr bool BF16 = CT == 1 || CT == 2;
+  static_assert(!DMA || (FAST && ALIGNED), "direct-to-LDS loads: FAST variants only");
   constexpr int NPL = CT == 2 ? 3 : 1;
   static_assert(!BF16 || FAST, "the bf16 variants use the FAST loader");
   // 8 waves: 2 along cout x 4 along k.  Tile BC x WKT with WKT = 128 (BC=128) or 256 (BC=64): every wave
@@ -128,9 +138,10 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   constexpr int SWZ_X = NT == 2 ? 32 : 0;
   static_assert(XRPT % 2 == 0 && DRPT % 2 == 0, "row parity of a loader thread must not change between passes");
   // one allocation: fp32 mode carves double-buffered dy / x tiles (one barrier per step), the bf16 modes their images
-  __shared__ __attribute__((aligned(16))) float smem[2 * WP * BC + 2 * WP * WKT];
+  __shared__ __attribute__((aligned(16))) float smem[2 * WP * BC + 2 * WP * WKT + (DMA ? DMA_MAX_HW : 0)];
   float* const Ds = smem;
   float* const Xs = smem + 2 * WP * BC;
+  int* const offtab = reinterpret_cast<int*>(smem + 2 * WP * BC + 2 * WP * WKT);   // DMA: rowoff[Ho], coloff[Wo]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -148,7 +159,8 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   int ekh[4], ekw[4], eci[4];
   bool eok[4];
   if constexpr (ALIGNED) {
-    int k = kc0 + xq * 4;
+    // DMA: the lane's LDS position is fixed (wave base + 16 B * lane), so the swizzle is applied to what it fetches
+    int k = kc0 + (DMA ? (xq ^ (((xr0 & 1) ? SWZ_X : 0) >> 2)) : xq) * 4;
     eok[0] = k < p.Ktot;
     int kk = eok[0] ? k : 0;
     int tap = kk / p.Cin;
@@ -170,6 +182,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   // dy-tile loader: thread -> (row = tid / DQ + DRPT * i, q = tid % DQ)
   const int dq = tid % DQ;
   const int dr0 = tid / DQ;
+  const int dq_g = DMA ? (dq ^ (((dr0 & 1) ? SWZ_D : 0) >> 2)) : dq;   // global float4 column this thread fetches
   // LDS destinations of this thread's float4s (row parity is the same for all of its rows)
   const int xs_col = (xq * 4) ^ ((xr0 & 1) ? SWZ_X : 0);
   const int ds_col = (dq * 4) ^ ((dr0 & 1) ? SWZ_D : 0);
@@ -205,9 +218,9 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   if constexpr (FAST) {
 #pragma unroll
     for (int i = 0; i < DROWS; ++i)
-      dp_off[i] = dp_b[i] * (int)p.dy_sb + dp_oh[i] * (int)p.dy_sh + dp_ow[i] * p.dy_sw + (int)p.dy_off + co0 + dq * 4;
+      dp_off[i] = dp_b[i] * (int)p.dy_sb + dp_oh[i] * (int)p.dy_sh + dp_ow[i] * p.dy_sw + (int)p.dy_off + co0 + dq_g * 4;
   }
-  const bool d_col_ok = co0 + dq * 4 < p.Cout;
+  const bool d_col_ok = co0 + dq_g * 4 < p.Cout;
 
   auto load_tiles = [&](int mbase) {
     if constexpr (FAST) {
@@ -297,6 +310,65 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
         }
       }
       rd[i] = v;
+    }
+  };
+  // ---- direct-to-LDS loader -------------------------------------------------------------------------------------
+  constexpr int OFF_NONE = -(1 << 30);   // rowoff / coloff of a tap position in zero padding: any sum with it stays negative
+  if constexpr (DMA) {
+    // one tap per block (Cin % WKT == 0): float offset of the gathered row / column inside a sample
+    for (int t = tid; t < p.Ho + p.Wo; t += WTHR) {
+      if (t < p.Ho) {
+        const int ih = src_coord(t * p.stride - p.pad + ekh[0], p.Hu, p.ups, p.reflect);
+        offtab[t] = ih >= 0 ? ih * p.W * p.Cin : OFF_NONE;
+      } else {
+        const int iw = src_coord((t - p.Ho) * p.stride - p.pad + ekw[0], p.Wu, p.ups, p.reflect);
+        offtab[t] = iw >= 0 ? iw * p.Cin : OFF_NONE;
+      }
+    }
+    __syncthreads();
+  }
+  const int hwc = p.H * p.W * p.Cin;
+  auto dma_tiles = [&](int mbase, int buf) {
+    if constexpr (DMA) {
+      const int w = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) {
+        const int m = mbase + xr0 + XRPT * i;
+        const int off = px_b[i] * hwc + offtab[px_oh[i]] + offtab[p.Ho + px_ow[i]] + eci[0];
+        const bool ok = m < m_end && eok[0] && off >= 0;
+        const float* g = ok ? p.x + off : munit_wgrad_zero16;
+        // wave w fills rows [w * 64 / XQ, ...) of pass i: 1 KiB per wave instruction, lane l lands at base + 16 B * l
+        float* l = Xs + buf * (WP * WKT) + (XRPT * i) * WKT + w * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        int ow = px_ow[i] + step_w;
+        const bool cw = ow >= p.Wo;
+        ow -= cw ? p.Wo : 0;
+        int oh = px_oh[i] + step_h + (cw ? 1 : 0);
+        const bool ch = oh >= p.Ho;
+        oh -= ch ? p.Ho : 0;
+        px_ow[i] = ow;
+        px_oh[i] = oh;
+        px_b[i] += step_b + (ch ? 1 : 0);
+      }
+#pragma unroll
+      for (int i = 0; i < DROWS; ++i) {
+        const int m = mbase + dr0 + DRPT * i;
+        const bool ok = m < m_end && d_col_ok;
+        const float* g = ok ? p.dy + dp_off[i] : munit_wgrad_zero16;
+        float* l = Ds + buf * (WP * BC) + (DRPT * i) * BC + w * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        int ow = dp_ow[i] + step_w;
+        const bool cw = ow >= p.Wo;
+        ow -= cw ? p.Wo : 0;
+        int oh = dp_oh[i] + step_h + (cw ? 1 : 0);
+        const bool ch = oh >= p.Ho;
+        oh -= ch ? p.Ho : 0;
+        dp_ow[i] = ow;
+        dp_oh[i] = oh;
+        dp_off[i] += d_step + (cw ? d_carry_w : 0) + (ch ? d_carry_h : 0);
+      }
     }
   };
   constexpr int NXI = WKT / 128;              // X images per buffer (BF16 mode); image 0 of a buffer is dy
@@ -443,7 +515,27 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
 
   // same pipeline as conv_igemm_kernel: registers hold step s+1 while step s is multiplied out of LDS
   // buffer s&1; half-way they are written to the other buffer and the loads of step s+2 are issued.
-  if constexpr (CT == 2) {
+  if constexpr (DMA) {
+    // as conv_igemm_kernel's direct-to-LDS pipeline: the tile of step s+1 is issued into the other buffer at the top of
+    // step s and published by s_waitcnt vmcnt(0) + the one barrier
+    if (m_begin < m_end) dma_tiles(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int mb = m_begin; mb < m_end; mb += WP) {
+      if (mb + WP < m_end) dma_tiles(mb + WP, cur ^ 1);
+      compute_half(cur, 0);
+      compute_half(cur, WP / 2);
+      if (do_bias && tid < BC) {
+        const float* Dc = Ds + cur * (WP * BC);
+#pragma unroll 8
+        for (int r = 0; r < WP; ++r) bsum += Dc[r * BC + (tid ^ ((r & 1) ? SWZ_D : 0))];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else if constexpr (CT == 2) {
     // one buffer of three planes: barrier, split the registers into the planes, issue the next loads, barrier, multiply
     if (m_begin < m_end) load_tiles(m_begin);
     for (int mb = m_begin; mb < m_end; mb += WP) {
@@ -700,7 +792,10 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
                     (long long)p.B * p.H * p.W < (1ll << 23) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD");
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
-  if (fast && p.ct == 1) {
+  if (fast && p.ct == 0 && pl.bc == 128 && p.Cin % 128 == 0 && p.Ho + p.Wo <= DMA_MAX_HW &&
+      !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA")) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 3>), grid, dim3(WTHR), 0, st, p);
+  } else if (fast && p.ct == 1) {
     if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 1>), grid, dim3(WTHR), 0, st, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 1>), grid, dim3(WTHR), 0, st, p);
   } else if (fast && p.ct == 2) {

@@ -43,6 +43,11 @@ enum { MUNIT_PAD_ZERO = 0, MUNIT_PAD_REFLECT = 1 };
  * bf16 values (a = a0 + a1 + a2) and the six products a_i*b_j with i + j <= 2 are accumulated in fp32; the
  * dropped terms are <= 2^-24 |a||b|, below the rounding of an fp32 FMA chain.  Opt-in. */
 enum { MUNIT_COMPUTE_F32 = 0, MUNIT_COMPUTE_BF16 = 1, MUNIT_COMPUTE_F32X3 = 2 };
+/* Element type of an ACTIVATION tensor in HBM (BASELINE.json config #3: bf16 storage).  Parameters, biases, AdaIN
+ * parameters, norm statistics, accumulators, gradients of parameters and loss scalars are always fp32.  A bf16 tensor
+ * needs a channel count that is a multiple of 64 in the convolutions (one 128-byte tile row) and of 4 elsewhere;
+ * 3-channel images and 1x1-spatial vectors stay fp32.  Pointers of such tensors travel as void*. */
+enum { MUNIT_DTYPE_F32 = 0, MUNIT_DTYPE_BF16 = 1 };
 
 int munit_version(void);
 const char* munit_last_error(void);
@@ -71,27 +76,29 @@ typedef struct {
   int upsample;              /* 0 or 1: nearest x2 of x before padding */
   int act;                   /* MUNIT_ACT_* fused after bias (fwd only) */
   float slope;
-  int compute;               /* MUNIT_COMPUTE_*: arithmetic of the contraction (tensors are fp32 either way) */
+  int compute;               /* MUNIT_COMPUTE_*: arithmetic of the contraction */
+  int in_dtype, out_dtype;   /* MUNIT_DTYPE_* of x (and dx) / of y (and dy).  A bf16 x runs the bf16-storage kernels:
+                              * direct-to-LDS tiles of 64 channels, v_mfma_f32_16x16x32_bf16, bf16 weight image */
 } munit_conv_desc;
 
 int munit_conv2d_out_hw(const munit_conv_desc* d, int* Ho, int* Wo);
 
 size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d); /* 0 for most layers */
-int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w, const float* bias,
-                     float* y, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_conv2d_fwd(const munit_conv_desc* d, const void* x, const float* w, const float* bias,
+                     void* y, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* backward-data (autograd of the sites above): dx[B][H][W][Cin] from dy[B][Ho][Wo][Cout]
  * (dy is the gradient w.r.t. the PRE-activation output; use munit_act_bwd first when an
  * activation was fused).  Handles the adjoint of reflect padding (border fold-add) and of
  * the nearest upsample (2x2 sum).  If add != NULL, dx = result + add (same shape). */
 size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d);
-int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w, const float* add,
-                       float* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_conv2d_dgrad(const munit_conv_desc* d, const void* dy, const float* w, const void* add,
+                       void* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* backward-weight: dw = beta*dw + sum_m dy[m][co] * im2col(x)[m][kh][kw][ci], layout of w;
  * db = beta*db + sum_m dy[m][co] when db != NULL.  Deterministic split-K (slabs in ws). */
 size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d);
-int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
+int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, float* dw,
                        float* db, float beta, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* Prepared weight images.  Two passes multiply by a re-laid-out image of the layer's weights: backward-data
@@ -103,22 +110,23 @@ int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy
  * in DEVICE memory, one launch for every layer of an optimizer) and hand it to the *_prepared entry points.  With
  * wp == NULL those behave exactly like munit_conv2d_fwd / _dgrad (image rebuilt into the workspace per call). */
 enum { MUNIT_PASS_FWD = 0, MUNIT_PASS_DGRAD = 1, MUNIT_PASS_WGRAD = 2 };
-enum { MUNIT_PREP_NONE = 0, MUNIT_PREP_DGRAD = 1, MUNIT_PREP_SUBPIXEL = 2 };
+enum { MUNIT_PREP_NONE = 0, MUNIT_PREP_DGRAD = 1, MUNIT_PREP_SUBPIXEL = 2, MUNIT_PREP_CAST = 3 };
 typedef struct {
   const float* w; /* [Cout][KH][KW][Cin] */
-  float* wp;      /* image, munit_conv2d_prepared_weight_bytes() bytes */
+  float* wp;      /* image, munit_conv2d_prepared_weight_bytes() bytes (bf16 elements when bf16 != 0) */
   int Cout, KH, KW, Cin;
-  int kind;       /* MUNIT_PREP_* */
+  int kind;       /* MUNIT_PREP_*; _CAST = the weights as they are, rounded to bf16 (forward of a bf16-input layer) */
   int ps;         /* stride phases per axis (MUNIT_PREP_DGRAD) */
+  int bf16;       /* image in bf16: the pass runs the bf16-storage kernels */
 } munit_prep_item;
 size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, int pass);
 int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const float* w, float* wp, munit_prep_item* out);
 int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream);
 int munit_conv2d_prepare_weights_batch(const munit_prep_item* items_dev, int n, munit_stream_t stream);
-int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* x, const float* w, const float* wp,
-                              const float* bias, float* y, void* ws, size_t ws_bytes, munit_stream_t stream);
-int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float* dy, const float* w, const float* wp,
-                                const float* add, float* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x, const float* w, const void* wp,
+                              const float* bias, void* y, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void* dy, const float* w, const void* wp,
+                                const void* add, void* dx, void* ws, size_t ws_bytes, munit_stream_t stream);
 
 /* nn.Linear of LinearBlock (scripts/networks.py:712, 743-749) under its own name: y[B][N] = act(x[B][K] w[N][K]^T + bias),
  * i.e. the 1x1 convolution on a [B][1][1][K] image (same kernels).  bwd: dx (or NULL), dw = beta*dw + dy^T x and
@@ -161,6 +169,14 @@ int munit_instnorm_bwd(const float* x, const float* dy, const float* stats, floa
                        int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
                        int relu, void* ws, size_t ws_bytes, munit_stream_t stream);
 
+/* bf16-storage forms (x, y, dy, dx, residual are bf16 tensors; statistics, AdaIN parameters and their gradients fp32) */
+int munit_instnorm_fwd_bf16(const void* x, void* y, float* stats, int B, int HW, int C,
+                            const float* adain, int ad_ld, int w_off, int b_off, const void* residual,
+                            int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_instnorm_bwd_bf16(const void* x, const void* dy, const float* stats, void* dx, int B, int HW,
+                            int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
+                            int relu, void* ws, size_t ws_bytes, munit_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * MUNIT's custom LayerNorm (scripts/networks.py:851-878): per-sample mean and UNBIASED
  * std over C*H*W, y = act( (x - mean) / (std + eps) * gamma[c] + beta[c] ).
@@ -175,6 +191,15 @@ int munit_layernorm_bwd(const float* x, const float* dy, const float* stats, flo
                         int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
                         float acc, int relu, float eps, void* ws, size_t ws_bytes,
                         munit_stream_t stream);
+
+/* bf16-storage forms (x, y, dy, dx bf16; gamma, beta and their gradients fp32) */
+int munit_layernorm_fwd_bf16(const void* x, void* y, float* stats, int B, int HW, int C,
+                             const float* gamma, const float* beta, int relu, float eps, void* ws,
+                             size_t ws_bytes, munit_stream_t stream);
+int munit_layernorm_bwd_bf16(const void* x, const void* dy, const float* stats, void* dx, int B, int HW,
+                             int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                             float acc, int relu, float eps, void* ws, size_t ws_bytes,
+                             munit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Pooling.  nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)
@@ -197,6 +222,11 @@ int munit_l1_mean_fwd(const float* a, const float* b, const float* mask, size_t 
                       void* ws, size_t ws_bytes, munit_stream_t stream);
 int munit_l1_mean_bwd(const float* a, const float* b, const float* mask, size_t npix, int C,
                       const float* gout, float* da, float* db, munit_stream_t stream);
+/* recon_criterion on bf16 tensors (the content codes of the bf16-storage mode, trainer.py:470-471): a, b, da, db bf16 */
+int munit_l1_mean_fwd_bf16(const void* a, const void* b, const float* mask, size_t npix, int C, float* out,
+                           void* ws, size_t ws_bytes, munit_stream_t stream);
+int munit_l1_mean_bwd_bf16(const void* a, const void* b, const float* mask, size_t npix, int C,
+                           const float* gout, void* da, void* db, munit_stream_t stream);
 int munit_mse_const_fwd(const float* x, float target, size_t n, float* out, void* ws, size_t ws_bytes,
                         munit_stream_t stream);
 int munit_mse_const_bwd(const float* x, float target, size_t n, const float* gout, float* dx,

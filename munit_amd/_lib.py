@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MUNIT_HIP_LIB") or os.path.join(_HERE, "libmunit_hip.
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 PAD = {"zero": 0, "reflect": 1}
 COMPUTE = {"f32": 0, "bf16": 1, "f32x3": 2}
+DTYPE = {"f32": 0, "bf16": 1}     # MUNIT_DTYPE_*: element type of an activation tensor in HBM
 
 
 class ConvDesc(Structure):
@@ -22,13 +23,14 @@ class ConvDesc(Structure):
     _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("Cout", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("pad_mode", c_int),
-                ("upsample", c_int), ("act", c_int), ("slope", c_float), ("compute", c_int)]
+                ("upsample", c_int), ("act", c_int), ("slope", c_float), ("compute", c_int),
+                ("in_dtype", c_int), ("out_dtype", c_int)]
 
 
 class PrepItem(Structure):
     """munit_prep_item."""
     _fields_ = [("w", c_void_p), ("wp", c_void_p), ("Cout", c_int), ("KH", c_int), ("KW", c_int), ("Cin", c_int),
-                ("kind", c_int), ("ps", c_int)]
+                ("kind", c_int), ("ps", c_int), ("bf16", c_int)]
 
 
 class ImageDesc(Structure):
@@ -68,10 +70,17 @@ SIGNATURES = {
                                    c_float, _P, c_size_t, _P]),
     "munit_instnorm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
                                    _P, c_size_t, _P]),
+    "munit_instnorm_fwd_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int,
+                                        c_float, _P, c_size_t, _P]),
+    "munit_instnorm_bwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int,
+                                        _P, c_size_t, _P]),
     "munit_layernorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "munit_layernorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, c_size_t, _P]),
     "munit_layernorm_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int,
                                     c_float, _P, c_size_t, _P]),
+    "munit_layernorm_fwd_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, c_size_t, _P]),
+    "munit_layernorm_bwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int,
+                                         c_float, _P, c_size_t, _P]),
     "munit_avgpool3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "munit_avgpool3s2_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "munit_gap_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
@@ -79,6 +88,8 @@ SIGNATURES = {
     "munit_loss_workspace_bytes": (c_size_t, [c_size_t]),
     "munit_l1_mean_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P, _P, c_size_t, _P]),
     "munit_l1_mean_bwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P, _P, _P, _P]),
+    "munit_l1_mean_fwd_bf16": (c_int, [_P, _P, _P, c_size_t, c_int, _P, _P, c_size_t, _P]),
+    "munit_l1_mean_bwd_bf16": (c_int, [_P, _P, _P, c_size_t, c_int, _P, _P, _P, _P]),
     "munit_mse_const_fwd": (c_int, [_P, c_float, c_size_t, _P, _P, c_size_t, _P]),
     "munit_mse_const_bwd": (c_int, [_P, c_float, c_size_t, _P, _P, _P]),
     "munit_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _P, _P]),

@@ -9,6 +9,28 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// bf16 storage (MUNIT_DTYPE_BF16 tensors): activations of the bf16 mode live in HBM as bf16, every statistic,
+// accumulator, bias, parameter and loss stays fp32.  Conversions: plain casts (v_cvt_pk_bf16_f32, round-to-nearest-even,
+// NaN stays NaN).
+typedef __bf16 bf16_t;
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+
+// 4 consecutive elements of a float / bf16 tensor as fp32, and back
+__device__ inline f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline f32x4 ld4(const bf16_t* p) {
+  const bf16v4 h = *reinterpret_cast<const bf16v4*>(p);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ inline void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ inline void st4(bf16_t* p, f32x4 v) {
+  *reinterpret_cast<bf16v4*>(p) = bf16v4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+__device__ inline float ld1(const float* p) { return *p; }
+__device__ inline float ld1(const bf16_t* p) { return (float)*p; }
+__device__ inline void st1(float* p, float v) { *p = v; }
+__device__ inline void st1(bf16_t* p, float v) { *p = (bf16_t)v; }
+
 void munit_set_error(const char* fmt, ...);
 
 #define MUNIT_CHECK_ARG(cond, ...)         \
@@ -66,8 +88,10 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass);
 // conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side
 bool munit_small_fwd_supported(const munit_conv_desc* d);
 bool munit_small_wgrad_supported(const munit_conv_desc* d);
-int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* w, const float* bias,
+// x is read as d->in_dtype (fp32 or bf16); y is always fp32 (3 channels)
+int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* w, const float* bias,
                     float* y, hipStream_t st);
 size_t munit_small_wgrad_workspace(const munit_conv_desc* d, int Ho);
-int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* dy, float* dw,
+// x is read as d->in_dtype; dy (3 channels) is fp32
+int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* dy, float* dw,
                       float* db, float beta, void* ws, hipStream_t st);

@@ -18,10 +18,10 @@
 namespace {
 
 struct IgemmParams {
-  const float* x;
-  const float* w;
+  const float* x;     // bf16 storage (CT == 4): the bf16 tensor seen as a float tensor with Cin/2 channels
+  const float* w;     // likewise the bf16 weight image
   const float* bias;
-  float* y;
+  void* y;            // float or bf16 (out_bf16) elements; all y strides / offsets below are in ELEMENTS
   int B, H, W, Cin;   // source tensor
   int Hu, Wu, ups;    // upsampled extent (H << ups)
   int Ho, Wo, Cout;   // output grid / GEMM N
@@ -52,7 +52,19 @@ struct IgemmParams {
   float* slab;
   int ct;    // compute type (aligned variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3 split
   int patch; // ROLE 2: at most two padded positions per axis fold onto a pixel -> direct-to-LDS tiles + LDS patch
+  int out_bf16;   // the epilogue rounds to bf16 (bias + activation applied in fp32 first)
+  int bf16s;      // x and w are bf16 in HBM (see x): direct-to-LDS tiles of 64 bf16 per row, v_mfma_f32_16x16x32_bf16
 };
+
+// sum of packed bf16 octets (the LDS patch of the bf16-storage backward-data): fp32 adds, one rounding
+__device__ inline f32x4 bf16x8_add4(f32x4 l, f32x4 a, f32x4 b, f32x4 c) {
+  const bf16v8 L = __builtin_bit_cast(bf16v8, l), A = __builtin_bit_cast(bf16v8, a), B = __builtin_bit_cast(bf16v8, b),
+               C = __builtin_bit_cast(bf16v8, c);
+  bf16v8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((float)L[e] + (((float)A[e] + (float)B[e]) + (float)C[e]));
+  return __builtin_bit_cast(f32x4, r);
+}
 
 // row index -> (sample, output row, output column)
 __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, int& oh, int& ow) {
@@ -145,8 +157,13 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // staging, no ds_write); taps in zero padding read munit_zero_page.  Not for ROLE 2, which adds gathers.  Tiles are unpadded [row][32] floats (each wave instruction fills 8 rows
   // = 1 KiB); bank conflicts are avoided by a swizzle instead: the lane that lands at 16-byte position p of row r
   // fetches global chunk p ^ ((r >> 1) & 7), and the fragment reads undo it.
+  // CT == 4: bf16 STORAGE.  Activations and the weight image are bf16 in HBM; a 128-byte tile row is then 64 channels
+  // instead of 32 floats, which is the only thing that changes for the direct-to-LDS loader (the host hands it the
+  // tensors as float tensors with Cin/2 channels), the fragment ds_read_b128 now holds the 8 consecutive k of one
+  // v_mfma_f32_16x16x32_bf16 operand, and one MFMA replaces four.
   constexpr bool BF16 = CT == 1 || CT == 2;
-  constexpr bool DMA = CT == 3;
+  constexpr bool DMA = CT == 3 || CT == 4;
+  constexpr bool BF16S = CT == 4;
   static_assert(!DMA || (ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned variants only");
   // ROLE 2 with CT == 3 ("fold by LDS patch"): layers whose pad adjoint folds at most two padded positions per axis onto
   // a source pixel (no up-sampling; reflect pad 1 of the 3x3 resblock convs).  The primary position of every row is a
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   constexpr int CLD = BN + 4;   // row stride of the epilogue's C staging tile (floats): conflict-free b32 writes
   static_assert(BM * CLD <= 2 * (BM + BN) * LDS_LD, "C staging tile must fit in the operand buffers");
   // direct-to-LDS variant: unpadded tiles; with BN = 64 that is 48 KiB -> three blocks (6 waves per SIMD) per CU
-  constexpr int SMEM_FLOATS = CT == 3 ? (2 * (BM + BN) * 32 > BM * CLD ? 2 * (BM + BN) * 32 : BM * CLD) : 2 * (BM + BN) * LDS_LD;
+  constexpr int SMEM_FLOATS = DMA ? (2 * (BM + BN) * 32 > BM * CLD ? 2 * (BM + BN) * 32 : BM * CLD) : 2 * (BM + BN) * LDS_LD;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* const As = smem;
   float* const Bs = smem + 2 * BM * LDS_LD;
@@ -200,11 +217,11 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
 
   const float* __restrict__ xg = p.x;
   const float* __restrict__ wg = p.w;
-  float* __restrict__ yg = p.y;
+  long long y_base = 0;   // element offset of this launch phase inside y
   if (p.ps > 1) {
     const int pa = blockIdx.y / p.ps, pb = blockIdx.y % p.ps;
     wg += (long long)blockIdx.y * p.w_phase;
-    yg += (long long)pa * p.y_phase_row + (long long)pb * p.y_phase_col;
+    y_base = (long long)pa * p.y_phase_row + (long long)pb * p.y_phase_col;
   }
 
   // ---- loader coordinates ----
@@ -550,6 +567,15 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         a[mt] = *reinterpret_cast<const f32x4*>(&Ac[(wm * WM + mt * 16 + frag_row) * 32 + pos]);
+      if constexpr (BF16S) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                                  __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+        return;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -598,7 +624,8 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
       for (int i = 0; i < AROWS; ++i) {
         if ((aoffp[0][i] & aoffp[1][i] & aoffp[2][i]) >= 0) {   // any of the three offsets is valid (-1 = none)
           f32x4* l = reinterpret_cast<f32x4*>(smem + buf * (BM * 32) + (r0 + RSTEP * i) * 32 + c4 * 4);
-          *l = *l + ((xp[0][i] + xp[1][i]) + xp[2][i]);
+          if constexpr (BF16S) *l = bf16x8_add4(*l, xp[0][i], xp[1][i], xp[2][i]);
+          else *l = *l + ((xp[0][i] + xp[1][i]) + xp[2][i]);
         }
       }
     }
@@ -689,22 +716,40 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
     const int m = m0 + row;
     if (m >= p.M || n >= p.Cout) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CLD + cq * 4]);
-    float* dst;
     if (split) {
-      dst = sl + (long long)m * p.Cout + n;
-    } else {
-      int b, oh, ow;
-      decode_pixel(m, p.Ho, p.Wo, p.frame, b, oh, ow);
-      dst = yg + (long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n;
+      float* dst = sl + (long long)m * p.Cout + n;
+      if (vec) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act, p.slope);
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Cout) dst[e] = v[e];
+      }
+      continue;
     }
-    if (vec) {
-      *reinterpret_cast<f32x4*>(dst) = v;
-    } else {
+    int b, oh, ow;
+    decode_pixel(m, p.Ho, p.Wo, p.frame, b, oh, ow);
+    const long long off = y_base + (long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < p.Cout) dst[e] = v[e];
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + bv[e], p.act, p.slope);
+    if (p.out_bf16) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + off;
+      if (vec) {
+        st4(dst, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Cout) dst[e] = (bf16_t)v[e];
+      }
+    } else {
+      float* dst = reinterpret_cast<float*>(p.y) + off;
+      if (vec) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.Cout) dst[e] = v[e];
+      }
     }
   }
 }
@@ -722,10 +767,12 @@ __global__ void splitk_epilogue_kernel(IgemmParams p, int phases) {
     for (int k = 0; k < p.ksplit; ++k) s += p.slab[((long long)ph * p.ksplit + k) * per + r];
     int b, oh, ow;
     decode_pixel(m, p.Ho, p.Wo, p.frame, b, oh, ow);
-    float* yg = p.y;
-    if (p.ps > 1) yg += (long long)(ph / p.ps) * p.y_phase_row + (long long)(ph % p.ps) * p.y_phase_col;
+    long long off = (long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n;
+    if (p.ps > 1) off += (long long)(ph / p.ps) * p.y_phase_row + (long long)(ph % p.ps) * p.y_phase_col;
     const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
-    yg[(long long)b * p.y_sb + (long long)oh * p.y_sh + (long long)ow * p.y_sw + n] = apply_act(s + bv, p.act, p.slope);
+    const float res = apply_act(s + bv, p.act, p.slope);
+    if (p.out_bf16) reinterpret_cast<bf16_t*>(p.y)[off] = (bf16_t)res;
+    else reinterpret_cast<float*>(p.y)[off] = res;
   }
 }
 
@@ -749,14 +796,24 @@ __device__ inline void prep_dgrad_elem(const PrepItem& it, long long i) {
   int pa = ph / ps, pb = ph % ps;
   int kh = pa + ps * (TH - 1 - t);
   int kw = pb + ps * (TW - 1 - r);
-  it.wp[i] = it.w[(((long long)co * it.KH + kh) * it.KW + kw) * it.Cin + ci];
+  const float v = it.w[(((long long)co * it.KH + kh) * it.KW + kw) * it.Cin + ci];
+  if (it.bf16) reinterpret_cast<bf16_t*>(it.wp)[i] = (bf16_t)v;
+  else it.wp[i] = v;
 }
+
+// forward of the bf16-storage mode: the weights as they are, rounded to bf16
+__device__ inline void prep_cast_elem(const PrepItem& it, long long i) { reinterpret_cast<bf16_t*>(it.wp)[i] = (bf16_t)it.w[i]; }
 
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv: output pixel (2i+a, 2j+b) reads source rows
 // i-1, i, i+1 with the 5 kernel rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (same for
 // columns), so each of the 4 phases is a 3x3 conv over the source with summed weights: 36 instead of
 // 100 MACs per source pixel and channel pair.  wc: [phase = a*2+b][Cout][3][3][Cin].
 __device__ inline void prep_subpixel_elem(const PrepItem& it, long long i) {
+  const long long merged = (long long)4 * 9 * it.Cout * it.Cin;
+  if (i >= merged) {   // bf16 image only: copy of the 5x5 weights
+    reinterpret_cast<bf16_t*>(it.wp)[i] = (bf16_t)it.w[i - merged];
+    return;
+  }
   long long r = i;
   const int ci = (int)(r % it.Cin); r /= it.Cin;
   const int dw = (int)(r % 3); r /= 3;
@@ -772,11 +829,16 @@ __device__ inline void prep_subpixel_elem(const PrepItem& it, long long i) {
   float s = 0.f;
   for (int kh = h0; kh < h0 + hn; ++kh)
     for (int kw = w0; kw < w0 + wn; ++kw) s += it.w[(((long long)co * 5 + kh) * 5 + kw) * it.Cin + ci];
-  it.wp[i] = s;
+  if (it.bf16) reinterpret_cast<bf16_t*>(it.wp)[i] = (bf16_t)s;
+  else it.wp[i] = s;
 }
 
+// elements of an image.  The bf16 sub-pixel image is [4 merged 3x3 phase kernels][the 5x5 weights themselves] (the frame
+// launch of the sub-pixel forward multiplies by the latter).
 __host__ __device__ inline long long prep_elems(const PrepItem& it) {
-  return it.kind == MUNIT_PREP_SUBPIXEL ? (long long)4 * 9 * it.Cout * it.Cin : (long long)it.Cout * it.KH * it.KW * it.Cin;
+  const long long cc = (long long)it.Cout * it.Cin;
+  if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
+  return cc * it.KH * it.KW;
 }
 
 // blockIdx.y = item (DEV: table in device memory, one launch re-lays every weight of an optimizer; else the one
@@ -787,6 +849,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
   const long long total = prep_elems(it);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
+    else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
 }
@@ -801,8 +864,9 @@ int launch_prep_one(const PrepItem& it, hipStream_t st) {
 
 // Adjoint of (nearest x2 upsample) + (reflect | zero pad): gather-sum the padded-domain
 // gradient g[B][Hq][Wq][C] (rows/cols beyond Hq/Wq are zero) into dx[B][H][W][C].
-__global__ void fold_kernel(const float* __restrict__ g, const float* __restrict__ add,
-                            float* __restrict__ dx, int B, int H, int W, int C, int ups, int pad,
+template <typename T>
+__global__ void fold_kernel(const T* __restrict__ g, const T* __restrict__ add,
+                            T* __restrict__ dx, int B, int H, int W, int C, int ups, int pad,
                             int reflect, int Hq, int Wq) {
   const int C4 = C >> 2;
   const long long total = (long long)B * H * W * C4;
@@ -836,15 +900,13 @@ __global__ void fold_kernel(const float* __restrict__ g, const float* __restrict
           if (qr[a] >= Hq) continue;
           for (int c = 0; c < nc; ++c) {
             if (qc[c] >= Wq) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(
-                g + (((long long)b * Hq + qr[a]) * Wq + qc[c]) * C + c4 * 4);
-            s += v;
+            s += ld4(g + (((long long)b * Hq + qr[a]) * Wq + qc[c]) * C + c4 * 4);
           }
         }
       }
     }
-    if (add != nullptr) s += *reinterpret_cast<const f32x4*>(add + i * 4);
-    *reinterpret_cast<f32x4*>(dx + i * 4) = s;
+    if (add != nullptr) s += ld4(add + i * 4);
+    st4(dx + i * 4, s);
   }
 }
 
@@ -915,9 +977,18 @@ size_t splitk_bytes(int M, int Cout, int Ktot, int phases) {
 
 template <int ROLE>
 int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = nullptr, size_t slab_bytes = 0) {
-  const bool aligned = (p.Cin % BK == 0) && (p.w_row % 4 == 0);
   const int bn = p.Cout <= 64 ? 64 : 128;
   IgemmParams q = p;
+  if (p.bf16s) {
+    // bf16 tensors seen as float tensors with half the channels (a tile row is 128 bytes either way)
+    if (p.Cin % (2 * BK) != 0 || NWAVES != 8) {
+      munit_set_error("conv_igemm: bf16 storage needs a multiple of 64 input channels (got %d)", p.Cin);
+      return MUNIT_ERR_ARG;
+    }
+    q.Cin = p.Cin / 2; q.Ktot = p.Ktot / 2; q.w_row = p.w_row / 2; q.w_phase = p.w_phase / 2;
+    slab = nullptr;   // no split-K in this mode
+  }
+  const bool aligned = (q.Cin % BK == 0) && (q.w_row % 4 == 0);
   q.n_tiles = cdiv(p.Cout, bn);
   const int m_tiles = cdiv(p.M, BM);
   q.ksplit = 1;
@@ -932,7 +1003,16 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
   }
   dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, (unsigned)q.ksplit);
   dim3 block(NTHR);
-  if constexpr (ROLE == 2) {
+  if (p.bf16s) {
+    if constexpr (ROLE == 2) {
+      if (!p.patch || p.frame) {
+        munit_set_error("conv_igemm: bf16-storage folded backward-data exists for the LDS-patch form only");
+        return MUNIT_ERR_ARG;
+      }
+    }
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 4>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 4>), grid, block, 0, st, q);
+  } else if constexpr (ROLE == 2) {
     if (!aligned) {
       munit_set_error("conv_igemm: folded backward-data needs Cout %% 32 == 0");
       return MUNIT_ERR_ARG;
@@ -981,6 +1061,10 @@ int check_desc(const munit_conv_desc* d) {
   MUNIT_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "conv: upsample must be 0 or 1");
   MUNIT_CHECK_ARG(d->compute >= MUNIT_COMPUTE_F32 && d->compute <= MUNIT_COMPUTE_F32X3, "conv: bad compute mode %d", d->compute);
   MUNIT_CHECK_ARG(d->pad_mode == MUNIT_PAD_ZERO || d->pad_mode == MUNIT_PAD_REFLECT, "conv: bad pad mode");
+  MUNIT_CHECK_ARG((d->in_dtype == MUNIT_DTYPE_F32 || d->in_dtype == MUNIT_DTYPE_BF16) &&
+                  (d->out_dtype == MUNIT_DTYPE_F32 || d->out_dtype == MUNIT_DTYPE_BF16), "conv: bad tensor dtype");
+  MUNIT_CHECK_ARG(d->in_dtype == MUNIT_DTYPE_F32 || d->Cin % 64 == 0, "conv: a bf16 input needs Cin %% 64 == 0 (got %d)", d->Cin);
+  MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32 || d->Cout % 64 == 0, "conv: a bf16 output needs Cout %% 64 == 0 (got %d)", d->Cout);
   const int Hu = d->H << d->upsample, Wu = d->W << d->upsample;
   if (d->pad_mode == MUNIT_PAD_REFLECT)
     MUNIT_CHECK_ARG(d->pad < Hu && d->pad < Wu, "conv: reflect pad %d needs input > pad (got %dx%d)", d->pad, Hu, Wu);
@@ -1010,34 +1094,72 @@ bool subpixel_ok(const munit_conv_desc* d) {
 }
 }  // namespace
 
+namespace {
+// forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
+munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* wp) {
+  munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1, 0};
+  const bool small = munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD");
+  if (small) return it;
+  it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
+  if (subpixel_ok(d)) it.kind = MUNIT_PREP_SUBPIXEL;
+  else if (it.bf16) it.kind = MUNIT_PREP_CAST;
+  return it;
+}
+size_t prep_bytes(const munit_prep_item& it) {
+  return it.kind == MUNIT_PREP_NONE ? 0 : align_up((size_t)prep_elems(it) * (it.bf16 ? 2 : 4), 256);
+}
+}  // namespace
+
 extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
-  if (subpixel_ok(d))   // merged phase weights + split-K slabs of the frame launch (few tiles, 25-tap K)
-    return align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256) +
-           splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1);
-  if (munit_small_fwd_supported(d)) return 0;
-  return splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
+  // [weight image of the pass, when the caller keeps none][split-K slabs]
+  const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
+  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16) return img;
+  if (subpixel_ok(d))   // split-K slabs of the frame launch (few tiles, 25-tap K)
+    return img + splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1);
+  return img + splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
 }
 
-extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const float* x, const float* w,
-                                const float* bias, float* y, void* ws, size_t ws_bytes,
+extern "C" int munit_conv2d_fwd(const munit_conv_desc* d, const void* x, const float* w,
+                                const float* bias, void* y, void* ws, size_t ws_bytes,
                                 munit_stream_t stream) {
   return munit_conv2d_fwd_prepared(d, x, w, nullptr, bias, y, ws, ws_bytes, stream);
 }
 
-extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* x, const float* w, const float* wp,
-                                         const float* bias, float* y, void* ws, size_t ws_bytes,
+extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x, const float* w, const void* wp,
+                                         const float* bias, void* y, void* ws, size_t ws_bytes,
                                          munit_stream_t stream) {
   int Ho, Wo;
   int rc = munit_conv2d_out_hw(d, &Ho, &Wo);
   if (rc) return rc;
   MUNIT_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD"))
-    return munit_small_fwd(d, Ho, Wo, x, w, bias, y, st);
+  if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) {
+    MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32, "conv2d_fwd: the 3-channel image head writes fp32");
+    return munit_small_fwd(d, Ho, Wo, x, w, bias, reinterpret_cast<float*>(y), st);
+  }
+  const size_t need = munit_conv2d_fwd_workspace_bytes(d);
+  if (need != 0 && (ws == nullptr || ws_bytes < need)) {
+    munit_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+    return MUNIT_ERR_WORKSPACE;
+  }
+  // weight image of the pass: the caller's, or built into the head of the workspace
+  munit_prep_item it = fwd_prep_item(d, w, reinterpret_cast<float*>(ws));
+  const size_t img_bytes = prep_bytes(it);
+  const float* wimg = w;
+  if (it.kind != MUNIT_PREP_NONE) {
+    wimg = reinterpret_cast<const float*>(wp);
+    if (wimg == nullptr) {
+      rc = launch_prep_one(it, st);
+      if (rc) return rc;
+      wimg = it.wp;
+    }
+  }
+  void* slabs = ws ? reinterpret_cast<char*>(ws) + img_bytes : nullptr;
+  const size_t slab_bytes = ws ? ws_bytes - img_bytes : 0;
   IgemmParams p{};
-  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.x = reinterpret_cast<const float*>(x); p.w = wimg; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
   p.ups = d->upsample; p.Hu = d->H << p.ups; p.Wu = d->W << p.ups;
   p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
@@ -1052,23 +1174,12 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* 
   p.act = d->act; p.slope = d->slope;
   p.ct = d->compute;
   p.ps = 1;
-  if (subpixel_ok(d)) {
+  p.bf16s = d->in_dtype == MUNIT_DTYPE_BF16;
+  p.out_bf16 = d->out_dtype == MUNIT_DTYPE_BF16;
+  if (it.kind == MUNIT_PREP_SUBPIXEL) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
-    const size_t need = munit_conv2d_fwd_workspace_bytes(d);
-    if (ws == nullptr || ws_bytes < need) {
-      munit_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
-      return MUNIT_ERR_WORKSPACE;
-    }
-    const float* wc = wp;
-    if (wc == nullptr) {   // no prepared image from the caller: merge the phase weights into the workspace
-      PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_SUBPIXEL, 1};
-      rc = launch_prep_one(it, st);
-      if (rc) return rc;
-      wc = it.wp;
-    }
     IgemmParams q = p;
-    q.w = wc;
     q.ups = 0; q.Hu = d->H; q.Wu = d->W;
     q.Ho = d->H; q.Wo = d->W;                 // one GEMM row per source pixel and phase
     q.KH = 3; q.KW = 3; q.pad = 1; q.reflect = 0;
@@ -1084,10 +1195,12 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const float* 
     if (rc) return rc;
     p.frame = 1;
     p.M = d->B * (4 * Wo + 4 * (Ho - 4));
-    const size_t wc_bytes = align_up((size_t)4 * 9 * d->Cout * d->Cin * sizeof(float), 256);
-    return launch_igemm<0>(p, 1, st, reinterpret_cast<char*>(ws) + wc_bytes, ws_bytes - wc_bytes);
+    // the frame launch multiplies by the original 5x5 weights: fp32 -> w itself; bf16 storage -> their bf16 copy,
+    // which the image carries behind the merged phase weights
+    p.w = it.bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(wimg) + (size_t)4 * 9 * d->Cout * d->Cin) : w;
+    return launch_igemm<0>(p, 1, st, slabs, slab_bytes);
   }
-  return launch_igemm<0>(p, 1, st, ws, ws_bytes);
+  return launch_igemm<0>(p, 1, st, slabs, slab_bytes);
 }
 
 namespace {
@@ -1118,6 +1231,8 @@ struct DgradPlan {
   bool folded;  // stride-1, Cout % 32 == 0: pad/upsample adjoint folded into the gather (ROLE 2)
   bool small;   // 3 input channels, 7x7: padded-domain correlation on the thread-per-pixel VALU kernel
   bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
+  bool bf16s;   // dy (and the weight image) are bf16 in HBM: bf16-storage kernels (direct-to-LDS forms only)
+  bool patch;   // folded with at most two padded positions per axis: the LDS-patch form
   size_t wt_bytes, g_bytes, sk_bytes;
 };
 // number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
@@ -1163,12 +1278,24 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     if (pl->small) pl->folded = false;
     if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
   }
-  pl->boxsum = pl->folded && d->upsample == 1 && d->KH == 5 && d->pad == 2 && reflect && d->Cout % 32 == 0 &&
-               d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_BOXSUM");
-  pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(float), 256);
-  pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * sizeof(float), 256);
+  pl->patch = pl->folded && d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, reflect) <= 2 &&
+              max_fold_cands(d->W, 0, d->pad, reflect) <= 2;
+  // bf16 storage: dy is bf16 (d->out_dtype), dx / the padded-domain buffer g take d->in_dtype.  Only the direct-to-LDS
+  // forms exist in this mode: folded layers must be patchable, everything else runs as a plain correlation + fold_kernel
+  // (the up-sampling convs then issue all 100 MACs per source pixel: cheap on the bf16 pipe, and no box sum).
+  pl->bf16s = d->out_dtype == MUNIT_DTYPE_BF16 && !pl->small;
+  if (pl->bf16s && !pl->patch) pl->folded = false;
+  pl->boxsum = pl->folded && !pl->bf16s && d->in_dtype == MUNIT_DTYPE_F32 && d->upsample == 1 && d->KH == 5 && d->pad == 2 &&
+               reflect && d->Cout % 32 == 0 && d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_BOXSUM");
+  const size_t esz = d->in_dtype == MUNIT_DTYPE_BF16 ? 2 : 4;   // element size of dx and g
+  pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * (pl->bf16s ? 2 : 4), 256);
+  pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * esz, 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
   if (pl->boxsum) pl->g_bytes = align_up((size_t)d->B * pl->Ho * pl->Wo * d->Cout * sizeof(float), 256);  // S
+  if (pl->bf16s) {
+    pl->sk_bytes = 0;
+    return MUNIT_OK;
+  }
   if (pl->boxsum) {
     pl->sk_bytes = splitk_bytes(d->B * (4 * d->W + 4 * (d->H - 4)), d->Cin, d->KH * d->KW * d->Cout, 1);
     return MUNIT_OK;
@@ -1186,29 +1313,50 @@ extern "C" size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d) {
   return pl.wt_bytes + pl.g_bytes + pl.sk_bytes;
 }
 
-extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const float* dy, const float* w,
-                                  const float* add, float* dx, void* ws, size_t ws_bytes,
+extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const void* dy, const float* w,
+                                  const void* add, void* dx, void* ws, size_t ws_bytes,
                                   munit_stream_t stream) {
   return munit_conv2d_dgrad_prepared(d, dy, w, nullptr, add, dx, ws, ws_bytes, stream);
 }
 
-extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float* dy, const float* w, const float* wp,
-                                           const float* add, float* dx, void* ws, size_t ws_bytes,
+namespace {
+template <typename T>
+int launch_fold(const munit_conv_desc* d, const DgradPlan& pl, const void* g, const void* add, void* dx, hipStream_t st) {
+  const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+  long long total = (long long)d->B * d->H * d->W * (d->Cin / 4);
+  int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(fold_kernel<T>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const T*>(g),
+                     reinterpret_cast<const T*>(add), reinterpret_cast<T*>(dx), d->B, d->H, d->W, d->Cin, d->upsample,
+                     d->pad, reflect, pl.Hq, pl.Wq);
+  MUNIT_CHECK_LAUNCH("fold");
+  return MUNIT_OK;
+}
+}  // namespace
+
+extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void* dy_, const float* w, const void* wp,
+                                           const void* add_, void* dx_, void* ws, size_t ws_bytes,
                                            munit_stream_t stream) {
   DgradPlan pl;
   int rc = plan_dgrad(d, &pl);
   if (rc) return rc;
-  MUNIT_CHECK_ARG(dy && (w || wp) && dx && ws, "conv2d_dgrad: null pointer");
+  MUNIT_CHECK_ARG(dy_ && (w || wp) && dx_ && ws, "conv2d_dgrad: null pointer");
   if (ws_bytes < pl.wt_bytes + pl.g_bytes + pl.sk_bytes) {
     munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes + pl.sk_bytes);
     return MUNIT_ERR_WORKSPACE;
   }
+  // element types: dy = d->out_dtype, dx / add / g = d->in_dtype.  The fp32 names below keep the fp32 code readable; in
+  // the bf16 cases the pointers are only handed on (the kernels reinterpret them).
+  const float* dy = reinterpret_cast<const float*>(dy_);
+  const float* add = reinterpret_cast<const float*>(add_);
+  float* dx = reinterpret_cast<float*>(dx_);
+  const bool dx_bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
+  MUNIT_CHECK_ARG(!dx_bf16 || d->Cin % 4 == 0, "conv2d_dgrad: bf16 dx needs Cin %% 4 == 0");
   hipStream_t st = (hipStream_t)stream;
-  const float* wt = wp;
+  const float* wt = reinterpret_cast<const float*>(wp);
   float* g = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.wt_bytes);
   const bool direct = pl.direct && add == nullptr;
   if (wt == nullptr) {   // no prepared image from the caller: re-lay the weights into the workspace
-    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_DGRAD, pl.ps};
+    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_DGRAD, pl.ps, pl.bf16s ? 1 : 0};
     rc = launch_prep_one(it, st);
     if (rc) return rc;
     wt = it.wp;
@@ -1219,8 +1367,10 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
     munit_conv_desc t{};
     t.B = d->B; t.H = pl.Ho; t.W = pl.Wo; t.Cin = d->Cout; t.Cout = d->Cin; t.KH = pl.TH; t.KW = pl.TW;
     t.stride = 1; t.pad = pl.TH - 1; t.pad_mode = MUNIT_PAD_ZERO; t.upsample = 0; t.act = MUNIT_ACT_NONE;
+    t.in_dtype = d->out_dtype; t.out_dtype = MUNIT_DTYPE_F32;
     if (pl.small) {
-      rc = munit_small_fwd(&t, pl.Hq, pl.Wq, dy, wt, nullptr, g, st);
+      MUNIT_CHECK_ARG(!dx_bf16, "conv2d_dgrad: the 3-channel data gradient is fp32");
+      rc = munit_small_fwd(&t, pl.Hq, pl.Wq, dy_, wt, nullptr, g, st);
       if (rc) return rc;
       const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
       long long total = (long long)d->B * d->H * d->W * d->Cin;
@@ -1249,8 +1399,9 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
     p.ps = 1;
     p.f_pad = d->pad; p.f_ups = d->upsample; p.f_reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     p.f_Hu = d->H << d->upsample; p.f_Wu = d->W << d->upsample;
-    p.patch = d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, p.f_reflect) <= 2 &&
-              max_fold_cands(d->W, 0, d->pad, p.f_reflect) <= 2;
+    p.patch = pl.patch;
+    p.bf16s = pl.bf16s; p.out_bf16 = dx_bf16;
+    MUNIT_CHECK_ARG(!dx_bf16 || pl.bf16s || pl.patch, "conv2d_dgrad: unsupported dtype combination");
     if (pl.boxsum) {
       // interior source pixels 2..H-3 x 2..W-3: dx[i][j] = sum_taps wt[t][r] . S[2i-2+t][2j-2+r] -- one gather per element
       {
@@ -1276,6 +1427,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
     }
     if (rc) return rc;
     if (add != nullptr) {
+      MUNIT_CHECK_ARG(!dx_bf16, "conv2d_dgrad: `add` with a bf16 dx is not supported on the folded path");
       long long n = (long long)d->B * d->H * d->W * d->Cin;
       int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
       hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, dx, add, n);
@@ -1284,7 +1436,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
     return MUNIT_OK;
   }
   IgemmParams p{};
-  p.x = dy; p.w = wt; p.bias = nullptr; p.y = direct ? dx : g;
+  p.x = dy; p.w = wt; p.bias = nullptr; p.y = direct ? (void*)dx : (void*)g;
   p.B = d->B; p.H = pl.Ho; p.W = pl.Wo; p.Cin = d->Cout;
   p.ups = 0; p.Hu = pl.Ho; p.Wu = pl.Wo;
   p.Ho = pl.Ho + pl.TH - 1; p.Wo = pl.Wo + pl.TW - 1; p.Cout = d->Cin;
@@ -1303,22 +1455,21 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const float
   p.w_phase = (long long)d->Cin * p.Ktot;
   p.y_phase_row = (long long)pl.Wq * d->Cin;
   p.y_phase_col = d->Cin;
+  p.bf16s = pl.bf16s; p.out_bf16 = dx_bf16;
   rc = launch_igemm<1>(p, pl.ps * pl.ps, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
   if (rc) return rc;
   if (!direct) {
     const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
     if (d->Cin % 4 == 0) {
-      long long total = (long long)d->B * d->H * d->W * (d->Cin / 4);
-      int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-      hipLaunchKernelGGL(fold_kernel, dim3(blocks), dim3(256), 0, st, g, add, dx, d->B, d->H, d->W, d->Cin,
-                         d->upsample, d->pad, reflect, pl.Hq, pl.Wq);
+      rc = dx_bf16 ? launch_fold<bf16_t>(d, pl, g, add_, dx_, st) : launch_fold<float>(d, pl, g, add_, dx_, st);
+      if (rc) return rc;
     } else {
       long long total = (long long)d->B * d->H * d->W * d->Cin;
       int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
       hipLaunchKernelGGL(fold_scalar_kernel, dim3(blocks), dim3(256), 0, st, g, add, dx, d->B, d->H, d->W,
                          d->Cin, d->upsample, d->pad, reflect, pl.Hq, pl.Wq);
+      MUNIT_CHECK_LAUNCH("fold");
     }
-    MUNIT_CHECK_LAUNCH("fold");
   }
   return MUNIT_OK;
 }
@@ -1332,15 +1483,16 @@ extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const 
   if (rc) return rc;
   MUNIT_CHECK_ARG(out != nullptr, "conv2d_prep_item: null item");
   MUNIT_CHECK_ARG(pass == MUNIT_PASS_FWD || pass == MUNIT_PASS_DGRAD, "conv2d_prep_item: pass must be MUNIT_PASS_FWD or _DGRAD");
-  munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1};
+  munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1, 0};
   if (pass == MUNIT_PASS_FWD) {
-    if (subpixel_ok(d)) it.kind = MUNIT_PREP_SUBPIXEL;
+    it = fwd_prep_item(d, w, wp);
   } else {
     DgradPlan pl;
     rc = plan_dgrad(d, &pl);
     if (rc) return rc;
     it.kind = MUNIT_PREP_DGRAD;
     it.ps = pl.ps;
+    it.bf16 = pl.bf16s ? 1 : 0;
   }
   *out = it;
   return MUNIT_OK;
@@ -1349,12 +1501,13 @@ extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const 
 extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, int pass) {
   munit_prep_item it;
   if (munit_conv2d_prep_item(d, pass, nullptr, nullptr, &it) || it.kind == MUNIT_PREP_NONE) return 0;
-  return (size_t)prep_elems(it) * sizeof(float);
+  return (size_t)prep_elems(it) * (it.bf16 ? 2 : 4);
 }
 
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
-  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL, "conv2d_prepare_weights: bad kind %d", item->kind);
+  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || (item->kind == MUNIT_PREP_CAST && item->bf16),
+                  "conv2d_prepare_weights: bad kind %d", item->kind);
   MUNIT_CHECK_ARG(item->ps >= 1 && item->KH % item->ps == 0 && item->KW % item->ps == 0, "conv2d_prepare_weights: bad phase count");
   MUNIT_CHECK_ARG(item->kind != MUNIT_PREP_SUBPIXEL || (item->KH == 5 && item->KW == 5), "conv2d_prepare_weights: sub-pixel needs 5x5");
   return launch_prep_one(*item, (hipStream_t)stream);

@@ -16,7 +16,7 @@
 namespace {
 
 struct SmallParams {
-  const float* x;     // [B][H][W][Cin]
+  const void* x;      // [B][H][W][Cin], fp32 or bf16 (template parameter XT of the kernels)
   const float* w;     // [CO][K][K][Cin]
   const float* bias;  // [CO] or null
   const float* dy;    // wgrad: [B][Ho][Wo][CO]
@@ -38,7 +38,7 @@ __device__ inline int map_coord(int v, int n, int reflect) {
 // ---------------------------------------------------------------------------------------------
 // forward: thread per pixel, LDS halo patch, scalar weights.  Cin % 16 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int CO, int K>
+template <int CO, int K, typename XT>
 __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
   constexpr int TW = 64, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PLANE = PH * PW;
   __shared__ f32x4 patch[4 * PLANE];  // [c4][row][col]
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
   const int tile_y = bid % p.tiles_y;
   const int b = bid / p.tiles_y;
   const int ow0 = tile_x * TW, oh0 = tile_y * TH;
-  const float* xb = p.x + (long long)b * p.H * p.W * p.Cin;
+  const XT* xb = reinterpret_cast<const XT*>(p.x) + (long long)b * p.H * p.W * p.Cin;
   const float* __restrict__ wg = p.w;
 
   float acc[CO];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
       const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
       const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ih >= 0 && iw >= 0) v = *reinterpret_cast<const f32x4*>(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
+      if (ih >= 0 && iw >= 0) v = ld4(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
       patch[c4 * PLANE + pr * PW + pc] = v;
     }
     __syncthreads();
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
 // ---------------------------------------------------------------------------------------------
 // backward-weight: channel per lane; unit = (b, band of rows_per_unit output rows, kh, channel group)
 // ---------------------------------------------------------------------------------------------
-template <int CO, int K>
+template <int CO, int K, typename XT>
 __global__ __launch_bounds__(256) void conv_lanes_wgrad_kernel(SmallParams p) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(256) void conv_lanes_wgrad_kernel(SmallParams p) {
   for (int oh = oh_begin; oh < oh_end; ++oh) {
     const int ih = map_coord(oh - p.pad + kh, p.H, p.reflect);
     const bool rowok = ih >= 0;
-    const float* rowp = p.x + ((long long)b * p.H + (rowok ? ih : 0)) * p.W * p.Cin + ci;
+    const XT* rowp = reinterpret_cast<const XT*>(p.x) + ((long long)b * p.H + (rowok ? ih : 0)) * p.W * p.Cin + ci;
     const float* dyrow = p.dy + ((long long)b * p.Ho + oh) * p.Wo * CO;
     float win[K];
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
       const int iw = map_coord(j - p.pad, p.W, p.reflect);
-      win[j] = (rowok && iw >= 0) ? rowp[(long long)iw * p.Cin] : 0.f;
+      win[j] = (rowok && iw >= 0) ? ld1(rowp + (long long)iw * p.Cin) : 0.f;
     }
     for (int ow0 = 0; ow0 < p.Wo; ow0 += CH) {
       const int n = min(CH, p.Wo - ow0);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_lanes_wgrad_kernel(SmallParams p) {
         for (int s = 0; s < K; ++s) {
           const int i = i0 + s;  // pixels past n carry dy = 0 (lanes >= n loaded 0) and clamped loads
           const int iw = map_coord(min(ow0 + i, p.Wo - 1) + (K - 1) - p.pad, p.W, p.reflect);
-          win[(K - 1 + s) % K] = (rowok && iw >= 0) ? rowp[(long long)iw * p.Cin] : 0.f;
+          win[(K - 1 + s) % K] = (rowok && iw >= 0) ? ld1(rowp + (long long)iw * p.Cin) : 0.f;
 #pragma unroll
           for (int c = 0; c < CO; ++c) {
             const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dyv[c]), i));
@@ -212,7 +212,7 @@ bool munit_small_wgrad_supported(const munit_conv_desc* d) {
   return d->Cout == 3 && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->upsample == 0 && d->Cin % 64 == 0;
 }
 
-int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* w, const float* bias,
+int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* w, const float* bias,
                     float* y, hipStream_t st) {
   SmallParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
@@ -220,7 +220,8 @@ int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const float* x, co
   p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT; p.act = d->act; p.slope = d->slope;
   p.tiles_x = cdiv(Wo, 64); p.tiles_y = cdiv(Ho, 4);
   const long long blocks = (long long)d->B * p.tiles_x * p.tiles_y;
-  hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 7>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 7, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 7, float>), dim3((unsigned)blocks), dim3(256), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_patch_fwd");
   return MUNIT_OK;
 }
@@ -234,7 +235,7 @@ size_t munit_small_wgrad_workspace(const munit_conv_desc* d, int Ho) {
   return align_up((size_t)bands * ((size_t)3 * 49 * d->Cin + 3) * sizeof(float), 256);
 }
 
-int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const float* x, const float* dy, float* dw,
+int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* dy, float* dw,
                       float* db, float beta, void* ws, hipStream_t st) {
   SmallParams p{};
   p.x = x; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
@@ -244,7 +245,8 @@ int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const float* x, 
   const int G = d->Cin / 64;
   const long long bands = (long long)d->B * p.units_per_img;
   const long long units = bands * 7 * G;
-  hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, bf16_t>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, float>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_lanes_wgrad");
   const long long n_w = (long long)3 * 49 * d->Cin;
   const int blocks = cdiv(n_w + 3, 256);

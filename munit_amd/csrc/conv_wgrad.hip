@@ -11,12 +11,13 @@
 // (one wide read feeds 4 / 2 MFMA tiles, see Frag).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 struct WgradParams {
-  const float* x;
-  const float* dy;
+  const void* x;     // fp32, or bf16 when the kernel's XB is set
+  const void* dy;    // fp32, or bf16 when DYB is set
   float* slab;       // [nsplit][Cout][Ktot]
   float* bias_slab;  // [nsplit][Cout] or null
   int B, H, W, Cin, Hu, Wu, ups;
@@ -32,6 +33,7 @@ struct WgradParams {
   int frame;  // GEMM rows enumerate only the 2-pixel border frame of the Ho x Wo output (see decode_pixel)
   unsigned x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST loader (0 when >= 2 GiB)
   int ct;                      // compute type (FAST variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3
+  int x_bf16, dy_bf16;         // element types in HBM (FAST loader only)
 };
 
 // 16 bytes of zeros: rows past the end of a split / taps in zero padding are pointed here by the direct-to-LDS loader
@@ -114,9 +116,12 @@ __device__ inline int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (
 // travel global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no ds_write), and the gathered source offset
 // of an output pixel is rowoff[oh] + coloff[ow] from two small LDS tables built once per block (the reflect / zero-pad /
 // upsample coordinate map of that tap) instead of ~45 VALU instructions per row and step.
-template <int BC, bool ALIGNED, bool FAST, int CT = 0>
+// XB / DYB (FAST loader only): x / dy are bf16 tensors in HBM (bf16 storage mode); they are widened on load, so every
+// compute type works on them (CT 1 rounds back to the same bf16 values: exact).
+template <int BC, bool ALIGNED, bool FAST, int CT = 0, bool XB = false, bool DYB = false>
 __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   constexpr bool DMA = CT == 3;
+  static_assert(!(XB || DYB) || (FAST && !DMA), "bf16 tensors: FAST register loader only");
   constexpr bool BF16 = CT == 1 || CT == 2;
   static_assert(!DMA || (FAST && ALIGNED), "direct-to-LDS loads: FAST variants only");
   constexpr int NPL = CT == 2 ? 3 : 1;
@@ -224,8 +229,19 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
 
   auto load_tiles = [&](int mbase) {
     if constexpr (FAST) {
-      const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+      // 4 consecutive elements at element offset `off` (or zeros): 16 bytes of fp32, or 8 bytes of bf16 widened
+      auto fetch4 = [&](const __amdgpu_buffer_rsrc_t& res, bool ok, unsigned off, auto is_bf16) -> f32x4 {
+        if constexpr (decltype(is_bf16)::value) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(res, ok ? off * 2u : OOB, 0, 0);
+          const bf16v4 h = __builtin_bit_cast(bf16v4, raw);
+          return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+          return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res, ok ? off * 4u : OOB, 0, 0));
+        }
+      };
 #pragma unroll
       for (int i = 0; i < XROWS; ++i) {
         const int m = mbase + xr0 + XRPT * i;
@@ -234,8 +250,8 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
         const bool ok = m < m_end && eok[0] && ih >= 0 && iw >= 0;
         // 24-bit multiplies: the host checked B*H*W < 2^23 and x_bytes < 2^31
         const int pix = __mul24(__mul24(px_b[i], p.H) + ih, p.W) + iw;
-        const unsigned off = (unsigned)(__mul24(pix, p.Cin) + eci[0]) * 4u;
-        rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? off : OOB, 0, 0));
+        const unsigned off = (unsigned)(__mul24(pix, p.Cin) + eci[0]);
+        rx[i] = fetch4(xres, ok, off, std::integral_constant<bool, XB>{});
         // walk 32 pixels on
         int ow = px_ow[i] + step_w;
         const bool cw = ow >= p.Wo;
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
       for (int i = 0; i < DROWS; ++i) {
         const int m = mbase + dr0 + DRPT * i;
         const bool ok = m < m_end && d_col_ok;
-        rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dres, ok ? (unsigned)dp_off[i] * 4u : OOB, 0, 0));
+        rd[i] = fetch4(dres, ok, (unsigned)dp_off[i], std::integral_constant<bool, DYB>{});
         int ow = dp_ow[i] + step_w;
         const bool cw = ow >= p.Wo;
         ow -= cw ? p.Wo : 0;
@@ -277,14 +293,14 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
         int ih = src_coord(ih0 + ekh[0], p.Hu, p.ups, p.reflect);
         int iw = src_coord(iw0 + ekw[0], p.Wu, p.ups, p.reflect);
         if (mok && eok[0] && ih >= 0 && iw >= 0)
-          v = *reinterpret_cast<const f32x4*>(p.x + (base + (long long)ih * p.W + iw) * p.Cin + eci[0]);
+          v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + (base + (long long)ih * p.W + iw) * p.Cin + eci[0]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int ih = src_coord(ih0 + ekh[e], p.Hu, p.ups, p.reflect);
           int iw = src_coord(iw0 + ekw[e], p.Wu, p.ups, p.reflect);
           float s = 0.f;
-          if (mok && eok[e] && ih >= 0 && iw >= 0) s = p.x[(base + (long long)ih * p.W + iw) * p.Cin + eci[e]];
+          if (mok && eok[e] && ih >= 0 && iw >= 0) s = reinterpret_cast<const float*>(p.x)[(base + (long long)ih * p.W + iw) * p.Cin + eci[e]];
           v[e] = s;
         }
       }
@@ -296,8 +312,8 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
       const bool mok = m < m_end;
       int b, oh, ow;
       decode_pixel(mok ? m : 0, p.Ho, p.Wo, p.frame, b, oh, ow);
-      const float* ptr = p.dy + (long long)b * p.dy_sb + (long long)oh * p.dy_sh + (long long)ow * p.dy_sw +
-                         p.dy_off + co0 + dq * 4;
+      const float* ptr = reinterpret_cast<const float*>(p.dy) + (long long)b * p.dy_sb + (long long)oh * p.dy_sh +
+                         (long long)ow * p.dy_sw + p.dy_off + co0 + dq * 4;
       const int co = co0 + dq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (mok) {
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
         const int m = mbase + xr0 + XRPT * i;
         const int off = px_b[i] * hwc + offtab[px_oh[i]] + offtab[p.Ho + px_ow[i]] + eci[0];
         const bool ok = m < m_end && eok[0] && off >= 0;
-        const float* g = ok ? p.x + off : munit_wgrad_zero16;
+        const float* g = ok ? reinterpret_cast<const float*>(p.x) + off : munit_wgrad_zero16;
         // wave w fills rows [w * 64 / XQ, ...) of pass i: 1 KiB per wave instruction, lane l lands at base + 16 B * l
         float* l = Xs + buf * (WP * WKT) + (XRPT * i) * WKT + w * 256;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
       for (int i = 0; i < DROWS; ++i) {
         const int m = mbase + dr0 + DRPT * i;
         const bool ok = m < m_end && d_col_ok;
-        const float* g = ok ? p.dy + dp_off[i] : munit_wgrad_zero16;
+        const float* g = ok ? reinterpret_cast<const float*>(p.dy) + dp_off[i] : munit_wgrad_zero16;
         float* l = Ds + buf * (WP * BC) + (DRPT * i) * BC + w * 256;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -787,12 +803,29 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   p.pix_per_split = pl.pix_per_split;
   dim3 grid((unsigned)pl.k_tiles, (unsigned)pl.c_tiles, (unsigned)pl.nsplit);
   // FAST loader: 32-bit byte offsets and 24-bit multiplies (see the kernel)
-  const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, db_ = (long long)p.B * p.dy_sb * 4;
+  const long long xb = (long long)p.B * p.H * p.W * p.Cin * (p.x_bf16 ? 2 : 4), db_ = (long long)p.B * p.dy_sb * (p.dy_bf16 ? 2 : 4);
+  const bool any_bf16 = p.x_bf16 || p.dy_bf16;
   const bool fast = aligned && (p.Cout % 4 == 0) && !p.frame && xb < (1ll << 31) && db_ < (1ll << 31) &&
-                    (long long)p.B * p.H * p.W < (1ll << 23) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD");
+                    (long long)p.B * p.H * p.W < (1ll << 23) && (any_bf16 || !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD"));
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
-  if (fast && p.ct == 0 && pl.bc == 128 && p.Cin % 128 == 0 && p.Ho + p.Wo <= DMA_MAX_HW &&
+  if (any_bf16) {
+    // bf16 storage: only the FAST register loader reads bf16 tensors
+    if (!fast) {
+      munit_set_error("conv2d_wgrad: bf16 tensors need Cin %% 4 == 0, Cout %% 4 == 0 and tensors below 2 GiB");
+      return MUNIT_ERR_ARG;
+    }
+    if (p.x_bf16 && p.dy_bf16) {        // trunk layers: bf16 MFMA (operands are already bf16 values)
+      if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 1, true, true>), grid, dim3(WTHR), 0, st, p);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 1, true, true>), grid, dim3(WTHR), 0, st, p);
+    } else if (p.dy_bf16) {             // first layer: fp32 image (4-channel re-layout) against a bf16 dy, fp32 MFMA
+      if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 0, false, true>), grid, dim3(WTHR), 0, st, p);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 0, false, true>), grid, dim3(WTHR), 0, st, p);
+    } else {
+      munit_set_error("conv2d_wgrad: bf16 x with fp32 dy exists for the 3-channel image head only");
+      return MUNIT_ERR_ARG;
+    }
+  } else if (fast && p.ct == 0 && pl.bc == 128 && p.Cin % 128 == 0 && p.Ho + p.Wo <= DMA_MAX_HW &&
       !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA")) {
     hipLaunchKernelGGL((conv_wgrad_kernel<128, true, true, 3>), grid, dim3(WTHR), 0, st, p);
   } else if (fast && p.ct == 1) {
@@ -839,7 +872,8 @@ void plan_cin3(const munit_conv_desc* d, int Ho, int Wo, Cin3Plan* cp) {
 }
 
 bool subpixel_wgrad_ok(const munit_conv_desc* d) {
-  return d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
+  // (bf16 tensors take the direct 25-tap form: its frame launches use the generic loader, which reads fp32 only)
+  return d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
          d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 4 == 0 && d->H >= 3 && d->W >= 3 &&
          !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SUBPIXEL");
 }
@@ -891,7 +925,7 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   return cc * d->B * Ho * Wo * d->KH * d->KW;
 }
 
-extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, const float* dy, float* dw,
+extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, float* dw,
                                   float* db, float beta, void* ws, size_t ws_bytes,
                                   munit_stream_t stream) {
   int Ho, Wo;
@@ -904,10 +938,14 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
   }
   hipStream_t st = (hipStream_t)stream;
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD"))
-    return munit_small_wgrad(d, Ho, Wo, x, dy, dw, db, beta, ws, st);
+  {
+    MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32, "conv2d_wgrad: the 3-channel image head has an fp32 dy");
+    return munit_small_wgrad(d, Ho, Wo, x, reinterpret_cast<const float*>(dy), dw, db, beta, ws, st);
+  }
   const bool aligned = d->Cin % 4 == 0;
   WgradParams p{};
   p.x = x; p.dy = dy;
+  p.x_bf16 = d->in_dtype == MUNIT_DTYPE_BF16; p.dy_bf16 = d->out_dtype == MUNIT_DTYPE_BF16;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
   p.ups = d->upsample; p.Hu = d->H << p.ups; p.Wu = d->W << p.ups;
   p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
@@ -954,11 +992,12 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const float* x, cons
     float* dw4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cp.x4_bytes);
     void* slabs = reinterpret_cast<char*>(ws) + cp.x4_bytes + cp.dw4_bytes;
     const long long npix = (long long)d->B * d->H * d->W;
-    hipLaunchKernelGGL(pad3to4_kernel, dim3((unsigned)std::min<long long>((npix + 255) / 256, 8192)), dim3(256), 0, st, x,
-                       reinterpret_cast<f32x4*>(x4), npix);
+    hipLaunchKernelGGL(pad3to4_kernel, dim3((unsigned)std::min<long long>((npix + 255) / 256, 8192)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(x), reinterpret_cast<f32x4*>(x4), npix);
+    MUNIT_CHECK_ARG(d->in_dtype == MUNIT_DTYPE_F32, "conv2d_wgrad: 3-channel inputs are fp32");
     MUNIT_CHECK_LAUNCH("pad3to4");
     WgradParams q = p;
-    q.x = x4; q.Cin = 4; q.Ktot = d->KH * d->KW * 4;
+    q.x = x4; q.Cin = 4; q.Ktot = d->KH * d->KW * 4; q.x_bf16 = 0;
     q.ct = 0;   // 4 channels per tap: not a multiple of the bf16 K granularity, stays fp32
     rc = run_wgrad(q, cp.pl, true, dw4, db, 0.0f, beta, slabs, st);
     if (rc) return rc;

@@ -41,7 +41,8 @@ inline int pick_split(int B, int HW) {
 // instance norm
 // ---------------------------------------------------------------------------------------
 // partial[b][split][2][C] : sum(x - pivot), sum((x - pivot)^2), pivot = x[b][0][c]
-__global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(NT) void in_stats_kernel(const T* __restrict__ x, double* __restrict__ partial,
                                                       int HW, int C, int nsplit) {
   extern __shared__ double smd[];  // [PL][QB*4][2]
   double* sm = smd;
@@ -50,13 +51,13 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ 
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
-  const float* xb = x + (long long)b * HW * C;
+  const T* xb = x + (long long)b * HW * C;
   for (int qq = q; qq < L.CQ; qq += L.QB) {
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
-      const f32x4 piv = *reinterpret_cast<const f32x4*>(xb + qq * 4);
+      const f32x4 piv = ld4(xb + qq * 4);
       for (int p = p0 + pl; p < p1; p += L.PL) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C + qq * 4) - piv;
+        f32x4 v = ld4(xb + (long long)p * C + qq * 4) - piv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           s1[e] += (double)v[e];
@@ -83,16 +84,17 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const float* __restrict__ 
 }
 
 // y = act((x-mean)*rstd*w + b) + residual ; writes stats[b][c] = (mean, rstd) from split 0
-__global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                       const double* __restrict__ partial, float* __restrict__ stats,
                                                       int HW, int C, int nsplit, const float* __restrict__ adain,
                                                       int ad_ld, int w_off, int b_off,
-                                                      const float* __restrict__ residual, int relu, float eps) {
+                                                      const T* __restrict__ residual, int relu, float eps) {
   extern __shared__ float sm[];  // scale[C], shift[C]
   float* scale = sm;
   float* shift = sm + C;
   const int b = blockIdx.y, sp = blockIdx.x;
-  const float* xb = x + (long long)b * HW * C;
+  const T* xb = x + (long long)b * HW * C;
   for (int c = threadIdx.x; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     for (int k = 0; k < nsplit; ++k) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ 
     }
     const double inv_n = 1.0 / (double)HW;
     const double d = s1 * inv_n;
-    const float mean = (float)((double)xb[c] + d);
+    const float mean = (float)((double)ld1(xb + c) + d);
     double var = s2 * inv_n - d * d;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ 
   const long long base = (long long)b * HW * C;
   for (long long i = i0 + threadIdx.x; i < i1; i += NT) {
     const int q = (int)(i % CQ);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i * 4);
+    f32x4 v = ld4(x + base + i * 4);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
     v = v * sc + sh;
@@ -134,13 +136,14 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
-    if (residual != nullptr) v += *reinterpret_cast<const f32x4*>(residual + base + i * 4);
-    *reinterpret_cast<f32x4*>(y + base + i * 4) = v;
+    if (residual != nullptr) v += ld4(residual + base + i * 4);
+    st4(y + base + i * 4, v);
   }
 }
 
 // backward partials: partial[b][split][2][C] : sum(g), sum(g*xhat), g = dy * relu'(pre)
-__global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ stats, double* __restrict__ partial,
                                                           int HW, int C, int nsplit, const float* __restrict__ adain,
                                                           int ad_ld, int w_off, int b_off, int relu) {
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restric
       }
       for (int p = p0 + pl; p < p1; p += L.PL) {
         const long long o = base + (long long)p * C + qq * 4;
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mean) * rstd;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 xh = (ld4(x + o) - mean) * rstd;
+        f32x4 g = ld4(dy + o);
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
@@ -198,9 +201,10 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const float* __restric
 }
 
 // dx = rstd*w*(g - mean(g) - xhat*mean(g*xhat)); d_adain weight = sum(g*xhat), bias = sum(g)
-__global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ stats,
-                                                          const double* __restrict__ partial, float* __restrict__ dx,
+                                                          const double* __restrict__ partial, T* __restrict__ dx,
                                                           int HW, int C, int nsplit, const float* __restrict__ adain,
                                                           float* __restrict__ d_adain, int ad_ld, int w_off, int b_off,
                                                           int relu) {
@@ -245,14 +249,14 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const float* __restric
     const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b + q * 4);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a1 + q * 4);
     const f32x4 a2 = *reinterpret_cast<const f32x4*>(s_a2 + q * 4);
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + base + i * 4) - mean) * rstd;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dy + base + i * 4);
+    const f32x4 xh = (ld4(x + base + i * 4) - mean) * rstd;
+    f32x4 g = ld4(dy + base + i * 4);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
     }
     const f32x4 r = rstd * w * (g - a1 - xh * a2);
-    *reinterpret_cast<f32x4*>(dx + base + i * 4) = r;
+    st4(dx + base + i * 4, r);
   }
 }
 
@@ -273,18 +277,19 @@ __device__ inline double block_sum(double v, double* red) {
 }
 
 // partial[b][split][2]: sum(x-pivot), sum((x-pivot)^2), pivot = x[b][0]
-__global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_stats_kernel(const T* __restrict__ x, double* __restrict__ partial,
                                                       long long n_per_sample, int nsplit) {
   __shared__ double red[NT / 64];
   const int b = blockIdx.y, sp = blockIdx.x;
-  const float* xb = x + (long long)b * n_per_sample;
+  const T* xb = x + (long long)b * n_per_sample;
   const long long nq = n_per_sample >> 2;
   const long long per = (nq + nsplit - 1) / nsplit;
   const long long q0 = sp * per, q1 = min(nq, q0 + per);
-  const float piv = xb[0];
+  const float piv = ld1(xb);
   double s1 = 0.0, s2 = 0.0;
   for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
+    f32x4 v = ld4(xb + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       double d = (double)(v[e] - piv);
@@ -300,7 +305,8 @@ __global__ __launch_bounds__(NT) void ln_stats_kernel(const float* __restrict__ 
   }
 }
 
-__device__ inline void ln_finish(const double* partial, const float* xb, int b, int nsplit, long long n,
+template <typename T>
+__device__ inline void ln_finish(const double* partial, const T* xb, int b, int nsplit, long long n,
                                  float* mean, float* sigma) {
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < nsplit; ++k) {
@@ -310,11 +316,12 @@ __device__ inline void ln_finish(const double* partial, const float* xb, int b, 
   const double d = s1 / (double)n;
   double var = (s2 - s1 * d) / (double)(n - 1);  // unbiased (torch.std default), networks.py:868/871
   if (var < 0.0) var = 0.0;
-  *mean = (float)((double)xb[0] + d);
+  *mean = (float)((double)ld1(xb) + d);
   *sigma = (float)sqrt(var);
 }
 
-__global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                       const double* __restrict__ partial, float* __restrict__ stats,
                                                       int HW, int C, int nsplit, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int relu, float eps) {
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ 
   float* shift = sm + C;
   const int b = blockIdx.y, sp = blockIdx.x;
   const long long n = (long long)HW * C;
-  const float* xb = x + (long long)b * n;
+  const T* xb = x + (long long)b * n;
   float mean, sigma;
   ln_finish(partial, xb, b, nsplit, n, &mean, &sigma);
   const float inv = 1.f / (sigma + eps);
@@ -342,20 +349,21 @@ __global__ __launch_bounds__(NT) void ln_apply_kernel(const float* __restrict__ 
   const long long q0 = sp * per, q1 = min(nq, q0 + per);
   for (long long i = q0 + threadIdx.x; i < q1; i += NT) {
     const int q = (int)(i % CQ);
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
+    f32x4 v = ld4(xb + i * 4);
     v = v * *reinterpret_cast<const f32x4*>(scale + q * 4) + *reinterpret_cast<const f32x4*>(shift + q * 4);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(y + (long long)b * n + i * 4) = v;
+    st4(y + (long long)b * n + i * 4, v);
   }
 }
 
 // backward partials. per (b, split): chan[2][C] = sum(g*xn), sum(g) per channel (g = dy*relu');
 // samp[2] = sum(g*gamma), sum(g*gamma*xn).
 // cpart layout [b][split][2][C], spart layout [b][split][2]
-__global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ stats, double* __restrict__ cpart,
                                                           double* __restrict__ spart, int HW, int C, int nsplit,
                                                           const float* __restrict__ gamma,
@@ -379,8 +387,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restric
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + qq * 4);
       for (int p = p0 + pl; p < p1; p += L.PL) {
         const long long o = base + (long long)p * C + qq * 4;
-        const f32x4 xn = (*reinterpret_cast<const f32x4*>(x + o) - mean) * inv;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 xn = (ld4(x + o) - mean) * inv;
+        f32x4 g = ld4(dy + o);
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
@@ -422,9 +430,10 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const float* __restric
 }
 
 // dx = inv*(h - S1/N) - S2*xn/((N-1)*sigma), h = g*gamma
-__global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ stats,
-                                                          const double* __restrict__ spart, float* __restrict__ dx,
+                                                          const double* __restrict__ spart, T* __restrict__ dx,
                                                           int HW, int C, int nsplit, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu, float eps) {
   const int b = blockIdx.y, sp = blockIdx.x;
@@ -448,14 +457,14 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
     const int q = (int)(i % CQ);
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
-    const f32x4 xn = (*reinterpret_cast<const f32x4*>(x + base + i * 4) - mean) * inv;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dy + base + i * 4);
+    const f32x4 xn = (ld4(x + base + i * 4) - mean) * inv;
+    f32x4 g = ld4(dy + base + i * 4);
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
     }
     const f32x4 r = (g * gm - c1) * inv - xn * c2;
-    *reinterpret_cast<f32x4*>(dx + base + i * 4) = r;
+    st4(dx + base + i * 4, r);
   }
 }
 
@@ -484,9 +493,10 @@ extern "C" size_t munit_instnorm_workspace_bytes(int B, int HW, int C) {
   return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256);
 }
 
-extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
-                                  const float* adain, int ad_ld, int w_off, int b_off, const float* residual,
-                                  int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
+namespace {
+template <typename T>
+int instnorm_fwd_t(const T* x, T* y, float* stats, int B, int HW, int C, const float* adain, int ad_ld, int w_off,
+                   int b_off, const T* residual, int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
   MUNIT_CHECK_ARG(x && y && stats && ws, "instnorm_fwd: null pointer");
   MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "instnorm_fwd: bad dims B=%d HW=%d C=%d", B, HW, C);
   MUNIT_CHECK_ARG(C <= 4096, "instnorm_fwd: C=%d too large", C);
@@ -498,18 +508,19 @@ extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B,
   const int ns = pick_split(B, HW);
   double* partial = reinterpret_cast<double*>(ws);
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(in_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
+  hipLaunchKernelGGL(in_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      partial, HW, C, ns);
   MUNIT_CHECK_LAUNCH("in_stats");
-  hipLaunchKernelGGL(in_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, partial,
+  hipLaunchKernelGGL(in_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, partial,
                      stats, HW, C, ns, adain, ad_ld, w_off, b_off, residual, relu, eps);
   MUNIT_CHECK_LAUNCH("in_apply");
   return MUNIT_OK;
 }
 
-extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
-                                  int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
-                                  int relu, void* ws, size_t ws_bytes, munit_stream_t stream) {
+template <typename T>
+int instnorm_bwd_t(const T* x, const T* dy, const float* stats, T* dx, int B, int HW, int C, const float* adain,
+                   float* d_adain, int ad_ld, int w_off, int b_off, int relu, void* ws, size_t ws_bytes,
+                   munit_stream_t stream) {
   MUNIT_CHECK_ARG(x && dy && stats && dx && ws, "instnorm_bwd: null pointer");
   MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "instnorm_bwd: bad dims");
   if (ws_bytes < munit_instnorm_workspace_bytes(B, HW, C)) {
@@ -520,13 +531,38 @@ extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* 
   const int ns = pick_split(B, HW);
   double* partial = reinterpret_cast<double*>(ws);
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(in_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
+  hipLaunchKernelGGL(in_bwd_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_stats");
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, stats,
+  hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, stats,
                      partial, dx, HW, C, ns, adain, d_adain, ad_ld, w_off, b_off, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_apply");
   return MUNIT_OK;
+}
+}  // namespace
+
+extern "C" int munit_instnorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                                  const float* adain, int ad_ld, int w_off, int b_off, const float* residual,
+                                  int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return instnorm_fwd_t<float>(x, y, stats, B, HW, C, adain, ad_ld, w_off, b_off, residual, relu, eps, ws, ws_bytes, stream);
+}
+extern "C" int munit_instnorm_fwd_bf16(const void* x, void* y, float* stats, int B, int HW, int C,
+                                       const float* adain, int ad_ld, int w_off, int b_off, const void* residual,
+                                       int relu, float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return instnorm_fwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), stats, B, HW, C, adain, ad_ld,
+                                w_off, b_off, reinterpret_cast<const bf16_t*>(residual), relu, eps, ws, ws_bytes, stream);
+}
+extern "C" int munit_instnorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                                  int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
+                                  int relu, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return instnorm_bwd_t<float>(x, dy, stats, dx, B, HW, C, adain, d_adain, ad_ld, w_off, b_off, relu, ws, ws_bytes, stream);
+}
+extern "C" int munit_instnorm_bwd_bf16(const void* x, const void* dy, const float* stats, void* dx, int B, int HW,
+                                       int C, const float* adain, float* d_adain, int ad_ld, int w_off, int b_off,
+                                       int relu, void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return instnorm_bwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), stats,
+                                reinterpret_cast<bf16_t*>(dx), B, HW, C, adain, d_adain, ad_ld, w_off, b_off, relu, ws, ws_bytes,
+                                stream);
 }
 
 extern "C" size_t munit_layernorm_workspace_bytes(int B, int HW, int C) {
@@ -534,9 +570,10 @@ extern "C" size_t munit_layernorm_workspace_bytes(int B, int HW, int C) {
          align_up((size_t)B * MAX_SPLIT * 2 * sizeof(double), 256);
 }
 
-extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
-                                   const float* gamma, const float* beta, int relu, float eps, void* ws,
-                                   size_t ws_bytes, munit_stream_t stream) {
+namespace {
+template <typename T>
+int layernorm_fwd_t(const T* x, T* y, float* stats, int B, int HW, int C, const float* gamma, const float* beta, int relu,
+                    float eps, void* ws, size_t ws_bytes, munit_stream_t stream) {
   MUNIT_CHECK_ARG(x && y && stats && gamma && beta && ws, "layernorm_fwd: null pointer");
   MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm_fwd: bad dims");
   MUNIT_CHECK_ARG((long long)HW * C > 1, "layernorm_fwd: unbiased std needs more than one element");
@@ -547,18 +584,18 @@ extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B
   hipStream_t st = (hipStream_t)stream;
   const int ns = pick_split(B, HW);
   double* spart = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(ln_stats_kernel, dim3(ns, B), dim3(NT), 0, st, x, spart, (long long)HW * C, ns);
+  hipLaunchKernelGGL(ln_stats_kernel<T>, dim3(ns, B), dim3(NT), 0, st, x, spart, (long long)HW * C, ns);
   MUNIT_CHECK_LAUNCH("ln_stats");
-  hipLaunchKernelGGL(ln_apply_kernel, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, spart, stats,
+  hipLaunchKernelGGL(ln_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, spart, stats,
                      HW, C, ns, gamma, beta, relu, eps);
   MUNIT_CHECK_LAUNCH("ln_apply");
   return MUNIT_OK;
 }
 
-extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
-                                   int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                   float acc, int relu, float eps, void* ws, size_t ws_bytes,
-                                   munit_stream_t stream) {
+template <typename T>
+int layernorm_bwd_t(const T* x, const T* dy, const float* stats, T* dx, int B, int HW, int C, const float* gamma,
+                    const float* beta, float* dgamma, float* dbeta, float acc, int relu, float eps, void* ws,
+                    size_t ws_bytes, munit_stream_t stream) {
   MUNIT_CHECK_ARG(x && dy && stats && dx && gamma && beta && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
   MUNIT_CHECK_ARG(B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 4096, "layernorm_bwd: bad dims");
   if (ws_bytes < munit_layernorm_workspace_bytes(B, HW, C)) {
@@ -571,14 +608,41 @@ extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float*
   double* spart = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) +
                                             align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256));
   const Lay L = make_lay(C);
-  hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
+  hipLaunchKernelGGL(ln_bwd_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      dy, stats, cpart, spart, HW, C, ns, gamma, beta, relu, eps);
   MUNIT_CHECK_LAUNCH("ln_bwd_stats");
-  hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(ns, B), dim3(NT), 0, st, x, dy, stats, spart, dx, HW, C, ns, gamma,
+  hipLaunchKernelGGL(ln_bwd_apply_kernel<T>, dim3(ns, B), dim3(NT), 0, st, x, dy, stats, spart, dx, HW, C, ns, gamma,
                      beta, relu, eps);
   MUNIT_CHECK_LAUNCH("ln_bwd_apply");
   hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(C), dim3(NT), 0, st, cpart, dgamma, dbeta, C, B * ns,
                      acc);
   MUNIT_CHECK_LAUNCH("ln_bwd_param");
   return MUNIT_OK;
+}
+}  // namespace
+
+extern "C" int munit_layernorm_fwd(const float* x, float* y, float* stats, int B, int HW, int C,
+                                   const float* gamma, const float* beta, int relu, float eps, void* ws,
+                                   size_t ws_bytes, munit_stream_t stream) {
+  return layernorm_fwd_t<float>(x, y, stats, B, HW, C, gamma, beta, relu, eps, ws, ws_bytes, stream);
+}
+extern "C" int munit_layernorm_fwd_bf16(const void* x, void* y, float* stats, int B, int HW, int C,
+                                        const float* gamma, const float* beta, int relu, float eps, void* ws,
+                                        size_t ws_bytes, munit_stream_t stream) {
+  return layernorm_fwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), stats, B, HW, C, gamma, beta,
+                                 relu, eps, ws, ws_bytes, stream);
+}
+extern "C" int munit_layernorm_bwd(const float* x, const float* dy, const float* stats, float* dx, int B, int HW,
+                                   int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                   float acc, int relu, float eps, void* ws, size_t ws_bytes,
+                                   munit_stream_t stream) {
+  return layernorm_bwd_t<float>(x, dy, stats, dx, B, HW, C, gamma, beta, dgamma, dbeta, acc, relu, eps, ws, ws_bytes, stream);
+}
+extern "C" int munit_layernorm_bwd_bf16(const void* x, const void* dy, const float* stats, void* dx, int B, int HW,
+                                        int C, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                        float acc, int relu, float eps, void* ws, size_t ws_bytes,
+                                        munit_stream_t stream) {
+  return layernorm_bwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), stats,
+                                 reinterpret_cast<bf16_t*>(dx), B, HW, C, gamma, beta, dgamma, dbeta, acc, relu, eps, ws,
+                                 ws_bytes, stream);
 }

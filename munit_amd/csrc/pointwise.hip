@@ -118,14 +118,15 @@ __device__ inline float block_sum256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(NT) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>
+__global__ __launch_bounds__(NT) void l1_partial_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         const float* __restrict__ mask, long long npix, int C,
                                                         float* __restrict__ partial) {
   __shared__ float red[4];
   const long long n = npix * C;
   float s = 0.f;
   for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
-    float d = fabsf(a[i] - b[i]);
+    float d = fabsf(ld1(a + i) - ld1(b + i));
     if (mask != nullptr) d *= (1.f - mask[i / C]);
     s += d;
   }
@@ -154,17 +155,18 @@ __global__ __launch_bounds__(NT) void finish_mean_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = (float)((double)s * inv_n);
 }
 
-__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask,
-                              long long npix, int C, const float* __restrict__ gout, float* __restrict__ da,
-                              float* __restrict__ db) {
+template <typename T>
+__global__ void l1_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ mask,
+                              long long npix, int C, const float* __restrict__ gout, T* __restrict__ da,
+                              T* __restrict__ db) {
   const long long n = npix * C;
   const float g = gout[0] / (float)n;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float d = a[i] - b[i];
+    const float d = ld1(a + i) - ld1(b + i);
     float s = d > 0.f ? g : (d < 0.f ? -g : 0.f);
     if (mask != nullptr) s *= (1.f - mask[i / C]);
-    if (da != nullptr) da[i] = s;
-    if (db != nullptr) db[i] = -s;
+    if (da != nullptr) st1(da + i, s);
+    if (db != nullptr) st1(db + i, -s);
   }
 }
 
@@ -298,14 +300,16 @@ constexpr int LOSS_PARTS = 1024;
 
 extern "C" size_t munit_loss_workspace_bytes(size_t) { return LOSS_PARTS * sizeof(float); }
 
-extern "C" int munit_l1_mean_fwd(const float* a, const float* b, const float* mask, size_t npix, int C, float* out,
-                                 void* ws, size_t ws_bytes, munit_stream_t stream) {
+namespace {
+template <typename T>
+int l1_mean_fwd_t(const T* a, const T* b, const float* mask, size_t npix, int C, float* out, void* ws, size_t ws_bytes,
+                  munit_stream_t stream) {
   MUNIT_CHECK_ARG(a && b && out && ws && npix > 0 && C > 0, "l1_mean_fwd: bad args");
   MUNIT_CHECK_ARG(ws_bytes >= LOSS_PARTS * sizeof(float), "l1_mean_fwd: workspace too small");
   const long long n = (long long)npix * C;
   const int parts = (int)std::min<long long>(LOSS_PARTS, (n + NT - 1) / NT);
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(l1_partial_kernel, dim3(parts), dim3(NT), 0, (hipStream_t)stream, a, b, mask, (long long)npix,
+  hipLaunchKernelGGL(l1_partial_kernel<T>, dim3(parts), dim3(NT), 0, (hipStream_t)stream, a, b, mask, (long long)npix,
                      C, partial);
   MUNIT_CHECK_LAUNCH("l1_partial");
   hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partial, parts, 1.0 / (double)n,
@@ -313,15 +317,35 @@ extern "C" int munit_l1_mean_fwd(const float* a, const float* b, const float* ma
   MUNIT_CHECK_LAUNCH("finish_mean");
   return MUNIT_OK;
 }
-
-extern "C" int munit_l1_mean_bwd(const float* a, const float* b, const float* mask, size_t npix, int C,
-                                 const float* gout, float* da, float* db, munit_stream_t stream) {
+template <typename T>
+int l1_mean_bwd_t(const T* a, const T* b, const float* mask, size_t npix, int C, const float* gout, T* da, T* db,
+                  munit_stream_t stream) {
   MUNIT_CHECK_ARG(a && b && gout && npix > 0 && C > 0, "l1_mean_bwd: bad args");
   const long long n = (long long)npix * C;
-  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n, 4)), dim3(NT), 0, (hipStream_t)stream, a, b, mask,
+  hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(grid_for(n, 4)), dim3(NT), 0, (hipStream_t)stream, a, b, mask,
                      (long long)npix, C, gout, da, db);
   MUNIT_CHECK_LAUNCH("l1_bwd");
   return MUNIT_OK;
+}
+}  // namespace
+
+extern "C" int munit_l1_mean_fwd(const float* a, const float* b, const float* mask, size_t npix, int C, float* out,
+                                 void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return l1_mean_fwd_t<float>(a, b, mask, npix, C, out, ws, ws_bytes, stream);
+}
+extern "C" int munit_l1_mean_fwd_bf16(const void* a, const void* b, const float* mask, size_t npix, int C, float* out,
+                                      void* ws, size_t ws_bytes, munit_stream_t stream) {
+  return l1_mean_fwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(a), reinterpret_cast<const bf16_t*>(b), mask, npix, C, out, ws,
+                               ws_bytes, stream);
+}
+extern "C" int munit_l1_mean_bwd(const float* a, const float* b, const float* mask, size_t npix, int C,
+                                 const float* gout, float* da, float* db, munit_stream_t stream) {
+  return l1_mean_bwd_t<float>(a, b, mask, npix, C, gout, da, db, stream);
+}
+extern "C" int munit_l1_mean_bwd_bf16(const void* a, const void* b, const float* mask, size_t npix, int C,
+                                      const float* gout, void* da, void* db, munit_stream_t stream) {
+  return l1_mean_bwd_t<bf16_t>(reinterpret_cast<const bf16_t*>(a), reinterpret_cast<const bf16_t*>(b), mask, npix, C, gout,
+                               reinterpret_cast<bf16_t*>(da), reinterpret_cast<bf16_t*>(db), stream);
 }
 
 extern "C" int munit_mse_const_fwd(const float* x, float target, size_t n, float* out, void* ws, size_t ws_bytes,

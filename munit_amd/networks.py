@@ -43,8 +43,8 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, pad, pad_type, upsample, act, slope)
+    def forward(self, x, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2, out_dtype=None):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, pad, pad_type, upsample, act, slope, out_dtype)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size,
@@ -182,13 +182,13 @@ class Conv2dBlock(nn.Module):
         self.activation = activation
         self.conv = Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
 
-    def forward(self, x, upsample=False, residual=None):
+    def forward(self, x, upsample=False, residual=None, out_dtype=None):
         if self.norm is None:
-            y = self.conv(x, self.pad.padding, self.pad.kind, upsample, self.activation)
+            y = self.conv(x, self.pad.padding, self.pad.kind, upsample, self.activation, out_dtype=out_dtype)
             if residual is not None:
                 raise NotImplementedError("munit_amd: residual add needs a normalised block")
             return y
-        y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none")
+        y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none", out_dtype=out_dtype)
         relu = self.activation == "relu"
         if isinstance(self.norm, LayerNorm):
             assert residual is None
@@ -300,10 +300,14 @@ class ContentEncoder(nn.Module):
         model += [ResBlocks(n_res, dim, norm=norm, activation=activ, pad_type=pad_type)]
         self.model = nn.Sequential(*model)
         self.output_dim = dim
+        # build extension (`precision: bf16s`, BASELINE.json config #3): element type in which this encoder's
+        # activations -- and through the content code everything the decoder computes up to its 3-channel image head --
+        # live in HBM.  None = fp32, the reference's.  The 3-channel input image is always fp32.
+        self.store_dtype = None
 
     def forward(self, x):
-        for m in self.model:
-            x = m(x)
+        for i, m in enumerate(self.model):
+            x = m(x, out_dtype=self.store_dtype) if (i == 0 and self.store_dtype is not None) else m(x)
         return x
 
 

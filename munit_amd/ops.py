@@ -44,9 +44,13 @@ _COMPUTE = 0
 
 
 def set_compute(mode):
+    """Arithmetic of the contractions.  "bf16s" (bf16 STORAGE, BASELINE.json config #3) multiplies like "bf16"; what it
+    adds -- bf16 activation tensors in HBM -- is a property of the tensors handed to the ops, not of this switch."""
     global _COMPUTE
+    if mode == "bf16s":
+        mode = "bf16"
     if mode not in COMPUTE:
-        raise ValueError("munit_amd: compute mode must be one of %s, got %r" % (sorted(COMPUTE), mode))
+        raise ValueError("munit_amd: compute mode must be one of %s, got %r" % (sorted(COMPUTE) + ["bf16s"], mode))
     _COMPUTE = COMPUTE[mode]
 
 
@@ -54,12 +58,20 @@ def get_compute():
     return [k for k, v in COMPUTE.items() if v == _COMPUTE][0]
 
 
-def _require(t, name="tensor"):
+def _require(t, name="tensor", bf16_ok=False):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("munit_amd: %s must live on a HIP device (no CPU fallback exists); got %s"
                            % (name, getattr(t, "device", type(t))))
-    if t.dtype != torch.float32:
-        raise RuntimeError("munit_amd: %s must be float32, got %s" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
+        raise RuntimeError("munit_amd: %s must be float32%s, got %s" % (name, " or bfloat16" if bf16_ok else "", t.dtype))
+
+
+def _dt(t):
+    """MUNIT_DTYPE_* of an activation tensor (or of a torch dtype)."""
+    return 1 if (t.dtype if isinstance(t, torch.Tensor) else t) == torch.bfloat16 else 0
+
+
+_TORCH_DT = (torch.float32, torch.bfloat16)
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream     # (device index) -> hipStream_t as int; no Stream object per call
@@ -93,8 +105,8 @@ def nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def empty_nhwc(b, c, h, w, like):
-    return torch.empty((b, c, h, w), device=like.device, dtype=torch.float32, memory_format=torch.channels_last)
+def empty_nhwc(b, c, h, w, like, dtype=torch.float32):
+    return torch.empty((b, c, h, w), device=like.device, dtype=dtype, memory_format=torch.channels_last)
 
 
 def workspace(nbytes, device, stream=None):
@@ -123,15 +135,15 @@ class _Plan(object):
 _plans = {}
 
 
-def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none", slope=0.2):
-    key = (b, h, w, cin, cout, kh, kw, stride, pad, pad_type, bool(upsample), act, slope, _COMPUTE)
+def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none", slope=0.2, in_dt=0, out_dt=0):
+    key = (b, h, w, cin, cout, kh, kw, stride, pad, pad_type, bool(upsample), act, slope, _COMPUTE, in_dt, out_dt)
     pl = _plans.get(key)
     if pl is not None:
         return pl
     lib = _lib.load()
     pl = _Plan()
     pl.d = ConvDesc(b, h, w, cin, cout, kh, kw, stride, pad, PAD[pad_type], int(bool(upsample)), ACT[act],
-                    float(slope), _COMPUTE)
+                    float(slope), _COMPUTE, in_dt, out_dt)
     pl.ref = byref(pl.d)
     ho, wo = c_int(), c_int()
     _lib.check(lib.munit_conv2d_out_hw(pl.ref, byref(ho), byref(wo)), "conv2d_out_hw")
@@ -216,7 +228,7 @@ def _prepared(owner, w, pl, which):
     lib = _lib.load()
     fresh = ent is None
     if fresh:
-        buf = torch.empty(pl.prep_bytes[which] // 4, dtype=torch.float32, device=w.device)
+        buf = torch.empty(pl.prep_bytes[which], dtype=torch.uint8, device=w.device)   # fp32 or bf16 image
         item = _lib.PrepItem()
         _lib.check(lib.munit_conv2d_prep_item(pl.ref, which, _p(w), _p(buf), byref(item)), "conv2d_prep_item")
         ent = [buf, ver, item]
@@ -243,7 +255,9 @@ def prepare_weights_batch(table, n):
 # ------------------------------------------------------------------------------------------
 # raw (non-autograd) entry points, also used by the tests
 # ------------------------------------------------------------------------------------------
-def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=0.2, owner=None):
+def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=0.2, owner=None, out_dtype=None):
+    """out_dtype: torch.float32 / torch.bfloat16 of y; default = x's dtype when Cout is a multiple of 64, else fp32
+    (3-channel images, small heads).  A bf16 x runs the bf16-storage kernels (weights stay fp32 parameters)."""
     lib = _lib.load()
     x, weight = nhwc(x), nhwc(weight)
     _same_device(x, weight, bias)
@@ -251,9 +265,11 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
     cout, cin_w, kh, kw = weight.shape
     if cin_w != cin:
         raise RuntimeError("munit_amd.conv2d: weight expects %d input channels, input has %d" % (cin_w, cin))
-    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act, slope)
+    if out_dtype is None:
+        out_dtype = x.dtype if cout % 64 == 0 else torch.float32
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act, slope, _dt(x), _dt(out_dtype))
     with _on(x):
-        y = empty_nhwc(b, cout, pl.ho, pl.wo, x)
+        y = empty_nhwc(b, cout, pl.ho, pl.wo, x, out_dtype)
         ws = workspace(pl.ws_fwd, x.device) if pl.ws_fwd else None
         wp = _prepared(owner, weight, pl, 0)
         if PROFILE is not None:
@@ -270,16 +286,18 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
     return y
 
 
-def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=None, owner=None):
+def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=None, owner=None,
+                     x_dtype=torch.float32):
+    """x_dtype: element type of the layer input, i.e. of the dx returned (dy carries the output's type)."""
     lib = _lib.load()
     dy, weight = nhwc(dy), nhwc(weight)
     _same_device(dy, weight, add)
     b, cin, h, w = x_shape
     cout, _, kh, kw = weight.shape
-    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample)
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, in_dt=_dt(x_dtype), out_dt=_dt(dy))
     with _on(dy):
         ws = workspace(pl.ws_dgrad, dy.device)
-        dx = empty_nhwc(b, cin, h, w, dy)
+        dx = empty_nhwc(b, cin, h, w, dy, x_dtype)
         if add is not None:
             add = nhwc(add)
         wp = _prepared(owner, weight, pl, 1)
@@ -298,7 +316,7 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
     _same_device(x, dy, dw, db)
     b, cin, h, w = x.shape
     cout, _, kh, kw = weight_shape
-    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample)
+    pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, in_dt=_dt(x), out_dt=_dt(dy))
     with _on(x):
         ws = workspace(pl.ws_wgrad, x.device, stream)
         if dw is None:
@@ -352,11 +370,13 @@ def join_side_streams():
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf, owner):
-        _require(x, "conv input")
+    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf, owner, out_dtype):
+        _require(x, "conv input", bf16_ok=True)
         _require(weight, "conv weight")
         x, w = nhwc(x), nhwc(weight)
-        y = conv2d_fwd_raw(x, w, bias, stride, pad, pad_type, upsample, act, slope, owner=owner)
+        y = conv2d_fwd_raw(x, w, bias, stride, pad, pad_type, upsample, act, slope, owner=owner, out_dtype=out_dtype)
+        if act != "none" and y.dtype != torch.float32:
+            raise RuntimeError("munit_amd.conv2d: a fused activation needs an fp32 output (bf16 layers are followed by a norm)")
         ctx.cfg = (stride, pad, pad_type, upsample, act, slope)
         ctx.has_bias = bias is not None
         ctx.wbuf = wbuf
@@ -388,21 +408,22 @@ class _Conv2d(Function):
                 conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
                                  want_bias=False)
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample, owner=ctx.owner)
+            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample, owner=ctx.owner, x_dtype=x.dtype)
         if want_w and ctx.wbuf is None:
             dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 def _gbuf(p):
     return getattr(p, "_munit_grad", None) if p is not None else None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2):
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2,
+           out_dtype=None):
     """pad -> conv -> bias -> activation (networks.py:695-701), optional fused nearest x2
-    upsample of the input (networks.py:534)."""
+    upsample of the input (networks.py:534).  out_dtype: see conv2d_fwd_raw."""
     return _Conv2d.apply(x, weight, bias, stride, pad, pad_type, upsample, act, slope, _gbuf(weight), _gbuf(bias),
-                         weight)
+                         weight, out_dtype)
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -413,7 +434,7 @@ def linear(x, weight, bias=None, act="none"):
     if wbuf is not None:
         wbuf = wbuf.view(n, k, 1, 1)
     y = _Conv2d.apply(x.reshape(b, k, 1, 1), weight.view(n, k, 1, 1), bias, 1, 0, "zero", False, act, 0.2, wbuf,
-                      _gbuf(bias), weight)
+                      _gbuf(bias), weight, torch.float32)
     return y.reshape(b, n)
 
 
@@ -421,7 +442,7 @@ class _InstNorm(Function):
     @staticmethod
     @_guarded
     def forward(ctx, x, adain, residual, w_off, b_off, relu, eps):
-        _require(x, "instance-norm input")
+        _require(x, "instance-norm input", bf16_ok=True)
         lib = _lib.load()
         x = nhwc(x)
         b, c, h, w = x.shape
@@ -436,9 +457,11 @@ class _InstNorm(Function):
             ld = adain.shape[1]
         if residual is not None:
             residual = nhwc(residual)
-        _lib.check(lib.munit_instnorm_fwd(_p(x), _p(y), _p(stats), b, h * w, c, _p(adain), ld, w_off, b_off,
-                                          _p(residual), int(relu), c_float(eps), _p(ws), ws.numel(), _stream()),
-                   "instnorm_fwd")
+            if residual.dtype != x.dtype:
+                raise RuntimeError("munit_amd.instance_norm: residual must have the input's dtype")
+        fn = lib.munit_instnorm_fwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_instnorm_fwd
+        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(adain), ld, w_off, b_off, _p(residual), int(relu),
+                      c_float(eps), _p(ws), ws.numel(), _stream()), "instnorm_fwd")
         ctx.cfg = (w_off, b_off, relu, ld)
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, stats, adain)
@@ -461,8 +484,11 @@ class _InstNorm(Function):
         if adain is not None and ctx.needs_input_grad[1]:
             d_adain = torch.zeros_like(adain)
         ws = workspace(lib.munit_instnorm_workspace_bytes(b, h * w, c), x.device)
-        _lib.check(lib.munit_instnorm_bwd(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(adain), _p(d_adain), ld,
-                                          w_off, b_off, int(relu), _p(ws), ws.numel(), _stream()), "instnorm_bwd")
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        fn = lib.munit_instnorm_bwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_instnorm_bwd
+        _lib.check(fn(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(adain), _p(d_adain), ld, w_off, b_off,
+                      int(relu), _p(ws), ws.numel(), _stream()), "instnorm_bwd")
         return dx, d_adain, (dy if ctx.has_res else None), None, None, None, None
 
 
@@ -481,15 +507,16 @@ class _LayerNorm(Function):
     @staticmethod
     @_guarded
     def forward(ctx, x, gamma, beta, relu, eps):
-        _require(x, "layer-norm input")
+        _require(x, "layer-norm input", bf16_ok=True)
         lib = _lib.load()
         x = nhwc(x)
         b, c, h, w = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((b, 2), device=x.device, dtype=torch.float32)
         ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
-        _lib.check(lib.munit_layernorm_fwd(_p(x), _p(y), _p(stats), b, h * w, c, _p(gamma), _p(beta), int(relu),
-                                           c_float(eps), _p(ws), ws.numel(), _stream()), "layernorm_fwd")
+        fn = lib.munit_layernorm_fwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_layernorm_fwd
+        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(gamma), _p(beta), int(relu), c_float(eps), _p(ws),
+                      ws.numel(), _stream()), "layernorm_fwd")
         ctx.cfg = (relu, eps)
         ctx.gbuf = getattr(gamma, "_munit_grad", None)
         ctx.bbuf = getattr(beta, "_munit_grad", None)
@@ -514,9 +541,12 @@ class _LayerNorm(Function):
         dgamma = ctx.gbuf if into else torch.empty_like(gamma)
         dbeta = ctx.bbuf if into else torch.empty_like(beta)
         ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
-        _lib.check(lib.munit_layernorm_bwd(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(gamma), _p(beta),
-                                           _p(dgamma), _p(dbeta), c_float(1.0 if into else 0.0), int(relu),
-                                           c_float(eps), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        fn = lib.munit_layernorm_bwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_layernorm_bwd
+        _lib.check(fn(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(gamma), _p(beta), _p(dgamma), _p(dbeta),
+                      c_float(1.0 if into else 0.0), int(relu), c_float(eps), _p(ws), ws.numel(), _stream()),
+                   "layernorm_bwd")
         if into or not want:
             return dx, None, None, None, None
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None,
@@ -590,11 +620,13 @@ class _L1Mean(Function):
     @staticmethod
     @_guarded
     def forward(ctx, a, b, mask):
-        _require(a, "l1 input")
-        _require(b, "l1 target")
+        _require(a, "l1 input", bf16_ok=True)
+        _require(b, "l1 target", bf16_ok=True)
         lib = _lib.load()
         if a.shape != b.shape:
             raise RuntimeError("munit_amd.l1_mean: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        if a.dtype != b.dtype:
+            raise RuntimeError("munit_amd.l1_mean: dtype mismatch %s vs %s" % (a.dtype, b.dtype))
         if a.dim() == 4:
             a, b = nhwc(a), nhwc(b)
             c = a.shape[1]
@@ -609,8 +641,8 @@ class _L1Mean(Function):
                 raise RuntimeError("munit_amd.l1_mean: mask must have one value per pixel (B,1,H,W)")
         out = torch.empty((), device=a.device, dtype=torch.float32)
         ws = workspace(lib.munit_loss_workspace_bytes(a.numel()), a.device)
-        _lib.check(lib.munit_l1_mean_fwd(_p(a), _p(b), _p(mask), npix, c, _p(out), _p(ws), ws.numel(), _stream()),
-                   "l1_mean_fwd")
+        fn = lib.munit_l1_mean_fwd_bf16 if a.dtype == torch.bfloat16 else lib.munit_l1_mean_fwd
+        _lib.check(fn(_p(a), _p(b), _p(mask), npix, c, _p(out), _p(ws), ws.numel(), _stream()), "l1_mean_fwd")
         ctx.c = c
         ctx.save_for_backward(a, b, mask)
         return out
@@ -623,8 +655,9 @@ class _L1Mean(Function):
         gout = gout.contiguous()
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.munit_l1_mean_bwd(_p(a), _p(b), _p(mask), a.numel() // ctx.c, ctx.c, _p(gout), _p(da), _p(db),
-                                         _stream()), "l1_mean_bwd")
+        fn = lib.munit_l1_mean_bwd_bf16 if a.dtype == torch.bfloat16 else lib.munit_l1_mean_bwd
+        _lib.check(fn(_p(a), _p(b), _p(mask), a.numel() // ctx.c, ctx.c, _p(gout), _p(da), _p(db), _stream()),
+                   "l1_mean_bwd")
         return da, db, None
 
 

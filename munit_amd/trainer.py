@@ -26,7 +26,7 @@ import torch.nn as nn
 from torch.optim import Optimizer
 
 from . import ops
-from .networks import AdaINGen, AdaINGen_double, InstanceNorm2d, MsImageDis
+from .networks import AdaINGen, AdaINGen_double, ContentEncoder, InstanceNorm2d, MsImageDis
 from .utils import get_model_list, get_scheduler, normalize_config, weights_init
 
 
@@ -254,6 +254,9 @@ class MUNIT_Trainer(nn.Module):
         # build extension (no reference counterpart): `precision: bf16` = BASELINE.json config #3 -- the conv /
         # linear contractions multiply bf16-rounded operands with fp32 accumulation; tensors, norm statistics,
         # losses and the optimizer stay fp32.  Default: the reference's fp32 arithmetic.
+        # `precision: bf16s` = bf16 STORAGE on top of that: the content encoders write bf16 activations, and the content
+        # code carries the type through the decoders up to the fp32 image head; norm statistics, AdaIN parameters,
+        # weights, gradients of weights, optimizer state, losses, the style encoder and the discriminators stay fp32.
         self.precision = hyperparameters.get("precision", "f32")
         ops.set_compute(self.precision)
 
@@ -271,6 +274,10 @@ class MUNIT_Trainer(nn.Module):
             self.gen = AdaINGen_double(hyperparameters["input_dim_a"], hyperparameters["gen"])
         else:
             raise ValueError("self.gen_state unknown value: %r" % (self.gen_state,))
+        if self.precision == "bf16s":
+            for m in self.modules():
+                if isinstance(m, ContentEncoder):
+                    m.store_dtype = torch.bfloat16
         self.dis_a = MsImageDis(hyperparameters["input_dim_a"], hyperparameters["dis"])
         self.dis_b = MsImageDis(hyperparameters["input_dim_b"], hyperparameters["dis"])
         self.instancenorm = InstanceNorm2d(512)

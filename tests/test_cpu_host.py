@@ -234,7 +234,7 @@ def test_compute_mode_plumbing_without_gpu():
     from munit_amd import _lib, ops
     assert _lib.COMPUTE == {"f32": 0, "bf16": 1, "f32x3": 2}
     fields = [f[0] for f in _lib.ConvDesc._fields_]
-    assert fields[-2:] == ["slope", "compute"] and ctypes.sizeof(_lib.ConvDesc) == 14 * 4
+    assert fields[-4:] == ["slope", "compute", "in_dtype", "out_dtype"] and ctypes.sizeof(_lib.ConvDesc) == 16 * 4
     assert ops.get_compute() == "f32"
     ops.set_compute("f32x3")
     assert ops.get_compute() == "f32x3"
@@ -242,7 +242,22 @@ def test_compute_mode_plumbing_without_gpu():
     with pytest.raises(ValueError):
         ops.set_compute("fp16")
     lib = _lib.load()
-    d = _lib.ConvDesc(1, 8, 8, 32, 32, 3, 3, 1, 1, 1, 0, 0, 0.0, 7)        # unknown compute mode
+    d = _lib.ConvDesc(1, 8, 8, 32, 32, 3, 3, 1, 1, 1, 0, 0, 0.0, 7, 0, 0)  # unknown compute mode
     ho, wo = ctypes.c_int(), ctypes.c_int()
     assert lib.munit_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) != 0
     assert b"compute" in lib.munit_last_error()
+    # bf16 storage plumbing: "bf16s" multiplies like "bf16"; tensor dtypes travel in the descriptor and are validated
+    ops.set_compute("bf16s")
+    assert ops.get_compute() == "bf16"
+    ops.set_compute("f32")
+    d = _lib.ConvDesc(1, 8, 8, 32, 64, 3, 3, 1, 1, 1, 0, 0, 0.0, 1, 1, 1)  # bf16 input with 32 channels: refused
+    assert lib.munit_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) != 0
+    assert b"Cin % 64" in lib.munit_last_error()
+    d = _lib.ConvDesc(2, 8, 8, 64, 128, 3, 3, 1, 1, 1, 0, 0, 0.0, 1, 1, 1)
+    assert lib.munit_conv2d_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    # the forward of a bf16-input layer multiplies by a bf16 copy of the weights; backward-data by the bf16 transpose
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d), 0) == 128 * 9 * 64 * 2
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d), 1) == 128 * 9 * 64 * 2
+    d32 = _lib.ConvDesc(2, 8, 8, 64, 128, 3, 3, 1, 1, 1, 0, 0, 0.0, 0, 0, 0)
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 0) == 0
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 1) == 128 * 9 * 64 * 4

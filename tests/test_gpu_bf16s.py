@@ -1,0 +1,203 @@
+"""GPU: bf16 STORAGE mode (`precision: bf16s`, BASELINE.json config #3 "256x256 batch 32 bf16"; a build extension with no
+reference counterpart -- the reference is fp32 throughout).  Activations of the content encoder /
+decoder trunk live in HBM as bf16; weights, norm statistics, AdaIN parameters, accumulators, weight gradients, losses stay
+fp32.  Checks, all against the fp64 oracle evaluated on the SAME bf16-valued inputs (so that only the kernel's own
+arithmetic is measured):
+  * a bf16 output must equal the fp64 result to bf16 rounding (2^-9 relative to the element, asserted as 8e-3 of the
+    tensor maximum) and fp32 outputs (weight gradients, statistics, the image head) to fp32-accumulation accuracy;
+  * the stated 2e-2 of the mode against the unrounded oracle, and the whole step against the fp32 step."""
+import pytest
+import torch
+
+from oracle import munit_oracle as O
+from tests.parity import nerr
+
+pytestmark = pytest.mark.gpu
+
+BF16_OUT = 8e-3        # bf16 rounding of an output tensor (normalised max)
+SHARP = 3e-5           # fp32 accumulation of exact bf16 products vs fp64
+MODE_TOL = 2e-2        # stated tolerance of the bf16 configuration vs the unrounded oracle
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def r16(t):
+    return t.float().bfloat16().double()
+
+
+def to_dev(t, dtype):
+    return t.to(dtype).to(dev()).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    from munit_amd import ops
+    ops.set_compute("bf16s")
+    yield
+    ops.set_compute("f32")
+
+
+BF, F32 = torch.bfloat16, torch.float32
+CASES = [
+    # cin, cout, k, stride, pad, ups, act, B, H, W, in dtype, out dtype
+    (64, 128, 4, 2, 1, 0, "none", 2, 16, 16, BF, BF),      # down-sampling (strided backward-data phases + fold)
+    (128, 256, 4, 2, 1, 0, "none", 1, 12, 20, BF, BF),
+    (256, 256, 3, 1, 1, 0, "none", 2, 8, 8, BF, BF),       # resblock conv (LDS-patch backward-data)
+    (256, 256, 3, 1, 1, 0, "none", 3, 33, 17, BF, BF),     # several tiles, ragged
+    (256, 128, 5, 1, 2, 1, "none", 2, 6, 8, BF, BF),       # up-sampling conv: sub-pixel forward, correlation + fold backward
+    (128, 64, 5, 1, 2, 1, "none", 1, 9, 7, BF, BF),
+    (3, 64, 7, 1, 3, 0, "none", 2, 20, 24, F32, BF),       # first layer: fp32 image in, bf16 out
+    (64, 3, 7, 1, 3, 0, "tanh", 2, 16, 12, BF, F32),       # image head: bf16 in, fp32 image out
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "c%d-%d_k%ds%d_u%d" % (c[0], c[1], c[2], c[3], c[5]))
+def test_conv_bf16_storage(case):
+    from munit_amd import ops
+    cin, cout, k, stride, pad, ups, act, B, H, W, din, dout = case
+    x = rnd((B, cin, H, W), 1)
+    w = rnd((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    b = rnd((cout,), 3, 0.1)
+    xq = r16(x) if din == BF else x.float().double()
+    wq = r16(w) if cin % 64 == 0 and cout != 3 else w.float().double()    # layers off the MFMA path multiply in fp32
+    xr, wr, br = xq.clone().requires_grad_(True), wq.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.conv_block(O.upsample2(xr) if ups else xr, wr, br, stride, pad, "reflect", None, act)
+    dy = rnd(tuple(yr.shape), 4)
+    dyq = r16(dy) if dout == BF else dy.float().double()
+    yr.backward(dyq)
+
+    xd = to_dev(xq, din).requires_grad_(True)
+    wd = w.float().to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.float().to(dev()).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride, pad, "reflect", bool(ups), act, out_dtype=dout)
+    assert y.dtype == dout and tuple(y.shape) == tuple(yr.shape)
+    loose = bool(ups)      # the sub-pixel form merges the 5x5 weights in fp32 BEFORE rounding them to bf16
+    assert nerr(y, yr) <= (MODE_TOL if loose else (BF16_OUT if dout == BF else 1e-4)), ("fwd", nerr(y, yr))
+    y.backward(to_dev(dyq, dout))
+    assert xd.grad.dtype == din
+    assert nerr(xd.grad, xr.grad) <= (BF16_OUT if din == BF else 1e-4), ("dx", nerr(xd.grad, xr.grad))
+    assert nerr(wd.grad, wr.grad) <= SHARP, ("dw", nerr(wd.grad, wr.grad))
+    assert nerr(bd.grad, br.grad) <= SHARP, ("db", nerr(bd.grad, br.grad))
+
+
+def test_prepared_bf16_images_follow_the_optimizer():
+    """The bf16 weight images of a layer bound to an optimizer are built once and refreshed by the optimizer step: the
+    forward after a step must use the new weights (not a stale image)."""
+    from munit_amd import ops
+    from munit_amd.trainer import FusedAdam
+    conv_w = torch.nn.Parameter((rnd((128, 64, 3, 3), 5, 0.05)).float().contiguous(memory_format=torch.channels_last))
+    opt = FusedAdam([conv_w], lr=1e-2, betas=(0.5, 0.999), weight_decay=0.0)
+    opt.bind(dev())
+    x = to_dev(r16(rnd((2, 64, 8, 8), 6)), BF)
+
+    def fwd():
+        return ops.conv2d(x, conv_w, None, 1, 1, "reflect", False, "none")
+
+    y0 = fwd()
+    ref0 = O.conv_block(x.double().cpu(), r16(conv_w.detach().cpu().double()), None, 1, 1, "reflect", None, "none")
+    assert nerr(y0, ref0) <= BF16_OUT
+    opt.zero_grad()
+    y0.float().pow(2).sum().backward()
+    torch.cuda.synchronize()
+    assert float(opt.flat_g.abs().max()) > 0
+    opt.step()
+    y1 = fwd()
+    ref1 = O.conv_block(x.double().cpu(), r16(conv_w.detach().cpu().double()), None, 1, 1, "reflect", None, "none")
+    assert nerr(ref1, ref0) > 1e-2              # the step really moved the weights
+    assert nerr(y1, ref1) <= BF16_OUT, nerr(y1, ref1)
+
+
+@pytest.mark.parametrize("kind", ["in", "in_relu_res", "adain", "ln"])
+def test_norms_bf16_storage(kind):
+    from munit_amd import ops
+    B, C, H, W = 2, 64, 12, 10
+    xq = r16(rnd((B, C, H, W), 7) * 2 + 0.5)
+    xr = xq.clone().requires_grad_(True)
+    xd = to_dev(xq, BF).requires_grad_(True)
+    extra_ref, extra_dev = [], []
+    if kind == "in":
+        yr = O.instance_norm(xr)
+        y = ops.instance_norm(xd)
+    elif kind == "in_relu_res":
+        rq = r16(rnd((B, C, H, W), 8))
+        yr = torch.clamp_min(O.instance_norm(xr), 0) * 0 + O.instance_norm(xr) + rq   # residual without relu (the network's use)
+        y = ops.instance_norm(xd, relu=False, residual=to_dev(rq, BF))
+    elif kind == "adain":
+        params = rnd((B, 2 * C), 9)
+        pr = params.clone().requires_grad_(True)
+        pd = params.float().to(dev()).requires_grad_(True)
+        yr = torch.clamp_min(O.adain(xr, pr[:, C:], pr[:, :C]), 0)
+        y = ops.adain(xd, pd, C, 0, relu=True)
+        extra_ref, extra_dev = [pr], [pd]
+    else:
+        gamma, beta = rnd((C,), 10).abs() + 0.1, rnd((C,), 11, 0.1)
+        gr, btr = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        gd, btd = gamma.float().to(dev()).requires_grad_(True), beta.float().to(dev()).requires_grad_(True)
+        yr = torch.clamp_min(O.munit_layer_norm(xr, gr, btr), 0)
+        y = ops.layer_norm(xd, gd, btd, relu=True)
+        extra_ref, extra_dev = [gr, btr], [gd, btd]
+    assert y.dtype == BF
+    assert nerr(y, yr) <= BF16_OUT, nerr(y, yr)
+    dyq = r16(rnd(tuple(yr.shape), 12))
+    # the ReLU mask of the reference must be the kernel's (taken from fp32 values before rounding): pin it via the output
+    yr.backward(dyq)
+    y.backward(to_dev(dyq, BF))
+    assert xd.grad.dtype == BF
+    assert nerr(xd.grad, xr.grad) <= 1.2e-2, ("dx", nerr(xd.grad, xr.grad))
+    for a, r in zip(extra_dev, extra_ref):
+        assert a.grad.dtype == F32 and nerr(a.grad, r.grad) <= 2e-3, nerr(a.grad, r.grad)
+
+
+def test_l1_bf16_storage():
+    from munit_amd import ops
+    a, b = r16(rnd((2, 64, 9, 7), 13)), r16(rnd((2, 64, 9, 7), 14))
+    ad, bd = to_dev(a, BF).requires_grad_(True), to_dev(b, BF).requires_grad_(True)
+    out = ops.l1_mean(ad, bd)
+    assert out.dtype == F32 and abs(float(out) - float((a - b).abs().mean())) <= 1e-5
+    out.backward()
+    g = torch.sign(a - b) / a.numel()
+    assert ad.grad.dtype == BF and nerr(ad.grad, g) <= BF16_OUT and nerr(bd.grad, -g) <= BF16_OUT
+
+
+def test_step_bf16_storage_tracks_fp32_step():
+    """One dis_update + gen_update with bf16 storage against the same step in fp32 (same weights, same batch): every
+    loss within the mode's stated 2e-2; the activations of the trunk are bf16, the images fp32."""
+    from munit_amd import ops
+    from munit_amd.trainer import MUNIT_Trainer
+    import bench
+    size, batch = 64, 2
+    x_a, x_b, m_a, m_b = (t.to(dev()) for t in bench.make_batch(batch, size))
+    out = {}
+    for prec in ("f32", "bf16s"):
+        hp = bench.bench_hp(size, batch)
+        hp["precision"] = prec
+        torch.manual_seed(1234)
+        tr = MUNIT_Trainer(hp)
+        tr.to(dev())
+        with torch.no_grad():
+            c, s = tr.gen.encode(x_a, 1)
+            img = tr.gen.decode(c, s, 1)
+        assert c.dtype == (BF if prec == "bf16s" else F32) and s.dtype == F32 and img.dtype == F32
+        torch.manual_seed(5)
+        tr.dis_update(x_a, x_b, hp)
+        tr.gen_update(x_a, x_b, hp, m_a, m_b)
+        names = [n for n in vars(tr) if n.startswith("loss_")]
+        out[prec] = ({n: float(getattr(tr, n)) for n in names}, tr.gen_opt.flat_g.detach().clone(), img.detach().clone())
+    ops.set_compute("bf16s")
+    lf, lb = out["f32"][0], out["bf16s"][0]
+    assert set(lf) == set(lb) and len(lf) >= 10
+    for n in lf:
+        assert abs(lb[n] - lf[n]) <= MODE_TOL * max(abs(lf[n]), 1e-3), (n, lf[n], lb[n])
+    assert nerr(out["bf16s"][2], out["f32"][2]) <= MODE_TOL * 2.5     # decoded image: eleven bf16 layers deep
+    # the flat generator gradient points the same way (cosine), and is finite everywhere
+    gf, gb = out["f32"][1].double(), out["bf16s"][1].double()
+    assert torch.isfinite(gb).all()
+    cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
+    assert cos > 0.98, cos

@@ -127,7 +127,7 @@ def test_norms_bf16_storage(kind):
         y = ops.instance_norm(xd)
     elif kind == "in_relu_res":
         rq = r16(rnd((B, C, H, W), 8))
-        yr = torch.clamp_min(O.instance_norm(xr), 0) * 0 + O.instance_norm(xr) + rq   # residual without relu (the network's use)
+        yr = O.instance_norm(xr) + rq          # residual without relu: the second conv of a ResBlock
         y = ops.instance_norm(xd, relu=False, residual=to_dev(rq, BF))
     elif kind == "adain":
         params = rnd((B, 2 * C), 9)

@@ -655,6 +655,168 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
   if (do_bias && tid < BC && co0 + tid < p.Cout) p.bias_slab[(long long)split * p.Cout + co0 + tid] = bsum;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 STORAGE backward-weight (x and dy are bf16 tensors): tile 128 (cout) x 128 (k), 64 pixels per step, both
+// operands travel global -> LDS directly (global_load_lds_dwordx4) into the [32 pixels][256 B] images that
+// ds_read_b64_tr_b16 reads (img_off: the lane picks the global 16-byte chunk that belongs at its fixed landing spot),
+// gathered source offsets come from the per-block LDS tables (one filter tap per block: Cin % 128 == 0),
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulators, partial slabs in fp32.  Against the register loader of the CT == 1
+// kernel (bf16 -> fp32 -> bf16 through VGPRs, 32-pixel steps) this is what a 16x faster matrix pipe needs: the loop is
+// bound by how fast tiles arrive, not by arithmetic.  Cout is padded to the 128-wide tile with zero rows.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BS_WP = 64;        // pixels per step
+__device__ const float munit_wgrad_zero16b[4] = {0.f, 0.f, 0.f, 0.f};
+
+__global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p) {
+  constexpr int BC = 128, WKT = 128, WC = 64, WK = 32, MT = 4, NT = 2;
+  constexpr int IMG = 8192;                 // one 32-pixel x 128-channel bf16 image
+  constexpr int STAGE = 4 * IMG;            // dy images 0,1 then x images 0,1
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * DMA_MAX_HW];
+  int* const offtab = reinterpret_cast<int*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int kc0 = blockIdx.x * WKT, co0 = blockIdx.y * BC, split = blockIdx.z;
+  const int m_begin = split * p.pix_per_split;
+  const int m_end = min(p.M, m_begin + p.pix_per_split);
+  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
+  const bf16_t* __restrict__ dyg = reinterpret_cast<const bf16_t*>(p.dy);
+
+  // the filter tap and first input channel of this block's 128 k-columns
+  const int tap = kc0 / p.Cin, ci0 = kc0 - tap * p.Cin;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  constexpr int OFF_NONE = -(1 << 30);
+  for (int t = tid; t < p.Ho + p.Wo; t += WTHR) {
+    if (t < p.Ho) {
+      const int ih = src_coord(t * p.stride - p.pad + kh, p.Hu, p.ups, p.reflect);
+      offtab[t] = ih >= 0 ? ih * p.W * p.Cin : OFF_NONE;
+    } else {
+      const int iw = src_coord((t - p.Ho) * p.stride - p.pad + kw, p.Wu, p.ups, p.reflect);
+      offtab[t] = iw >= 0 ? iw * p.Cin : OFF_NONE;
+    }
+  }
+
+  // loader: pass i (rows 32i .. 32i+31 = image i), row r = tid / 16, landing position pos = tid % 16 (16 bytes each);
+  // the image keeps global chunk c of row r at position c ^ f(r), so this lane fetches chunk pos ^ f(r)
+  const int r = tid >> 4, pos = tid & 15;
+  const int chunk = pos ^ (((r & 3) << 2) | ((r >> 2) & 3));
+  const int x_col = ci0 + 8 * chunk;                       // channel of x
+  const int d_col = co0 + 8 * chunk;                       // channel of dy
+  const bool d_ok = d_col < p.Cout;
+  int px_b[2], px_oh[2], px_ow[2], dp_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_begin + 32 * i + r;
+    decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, 0, px_b[i], px_oh[i], px_ow[i]);
+    dp_off[i] = px_b[i] * (int)p.dy_sb + px_oh[i] * (int)p.dy_sh + px_ow[i] * p.dy_sw + (int)p.dy_off + d_col;
+  }
+  const int hw = p.Ho * p.Wo;
+  const int step_b = BS_WP / hw;
+  const int step_h = (BS_WP - step_b * hw) / p.Wo;
+  const int step_w = BS_WP - step_b * hw - step_h * p.Wo;
+  const int d_step = step_b * (int)p.dy_sb + step_h * (int)p.dy_sh + step_w * p.dy_sw;
+  const int d_carry_w = (int)p.dy_sh - p.Wo * p.dy_sw;
+  const int d_carry_h = (int)p.dy_sb - p.Ho * (int)p.dy_sh;
+  const int hwc = p.H * p.W * p.Cin;
+  __syncthreads();   // tables
+
+  auto dma = [&](int mbase, int stage) {
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbase + 32 * i + r;
+      const bool mok = m < m_end;
+      const int xo = px_b[i] * hwc + offtab[px_oh[i]] + offtab[p.Ho + px_ow[i]] + x_col;
+      const void* gx = (mok && xo >= 0) ? (const void*)(xg + xo) : (const void*)munit_wgrad_zero16b;
+      const void* gd = (mok && d_ok) ? (const void*)(dyg + dp_off[i]) : (const void*)munit_wgrad_zero16b;
+      // wave w lands rows 4w .. 4w+3 of the image: 1 KiB per wave instruction, lane l at base + 16 l
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gd,
+                                       (__attribute__((address_space(3))) void*)(sb + i * IMG + 1024 * w), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                       (__attribute__((address_space(3))) void*)(sb + (2 + i) * IMG + 1024 * w), 16, 0, 0);
+      int ow = px_ow[i] + step_w;
+      const bool cw = ow >= p.Wo;
+      ow -= cw ? p.Wo : 0;
+      int oh = px_oh[i] + step_h + (cw ? 1 : 0);
+      const bool ch = oh >= p.Ho;
+      oh -= ch ? p.Ho : 0;
+      px_ow[i] = ow;
+      px_oh[i] = oh;
+      px_b[i] += step_b + (ch ? 1 : 0);
+      dp_off[i] += d_step + (cw ? d_carry_w : 0) + (ch ? d_carry_h : 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[a][t][e] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = p.bias_slab != nullptr && blockIdx.x == 0;
+  const int fj = lane & 15, fg = lane >> 4;
+  // operand of the 16-channel tile starting at channel c0: pixels 8 fg .. 8 fg + 7 of channel c0 + fj (see tr_frag of
+  // conv_wgrad_kernel: two transposed 4 x 16 block reads)
+  auto tr_frag = [&](const char* im, int c0) -> bf16x8 {
+    const int q = fj >> 2, pp = lane & 3;
+    const int ch = (c0 >> 3) + (pp >> 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(im + img_off(8 * fg + q, ch) + 8 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(im + img_off(8 * fg + 4 + q, ch) + 8 * (pp & 1)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  if (m_begin < m_end) dma(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int mb = m_begin; mb < m_end; mb += BS_WP) {
+    if (mb + BS_WP < m_end) dma(mb + BS_WP, cur ^ 1);
+    const char* sb = smem + cur * STAGE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // the two 32-pixel images of the stage: one MFMA contracts a whole image
+      bf16x8 hb[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) hb[u] = tr_frag(sb + (2 + h) * IMG, wn * WK + 16 * u);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const bf16x8 ha = tr_frag(sb + h * IMG, wm * WC + 16 * t);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[u], acc[t][u], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < BC) {
+#pragma unroll 8
+      for (int rr = 0; rr < BS_WP; ++rr)
+        bsum += (float)*reinterpret_cast<const bf16_t*>(sb + (rr >> 5) * IMG + img_off(rr & 31, tid >> 3) + 2 * (tid & 7));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // natural C/D map: accumulator (t, u), register e of lane (fj, fg) = cout row 16 t + 4 fg + e, k column 16 u + fj
+  float* out = p.slab + (long long)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + wm * WC + 16 * t + 4 * fg + e;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int k = kc0 + wn * WK + 16 * u + fj;
+        if (co < p.Cout && k < p.Ktot) out[(long long)co * p.Ktot + k] = acc[t][u][e];
+      }
+    }
+  if (do_bias && tid < BC && co0 + tid < p.Cout) p.bias_slab[(long long)split * p.Cout + co0 + tid] = bsum;
+}
+
 // dw[i] = beta*dw[i] + sum_s slab[s][i] (i < n) and, in the same launch, db[j] likewise from bias_slab
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
                                    const float* __restrict__ bias_slab, float* __restrict__ db, int nb,
@@ -814,6 +976,22 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
     if (!fast) {
       munit_set_error("conv2d_wgrad: bf16 tensors need Cin %% 4 == 0, Cout %% 4 == 0 and tensors below 2 GiB");
       return MUNIT_ERR_ARG;
+    }
+    if (p.x_bf16 && p.dy_bf16 && p.Cin % 128 == 0 && p.Cout % 8 == 0 && p.Ho + p.Wo <= DMA_MAX_HW &&
+        !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA")) {
+      // direct-to-LDS bf16 kernel: 128 x 128 tiles (Cout padded), 64-pixel steps; never more splits than the plan's slabs hold
+      int pps = (cdiv(p.M, pl.nsplit) + BS_WP - 1) / BS_WP * BS_WP;
+      p.pix_per_split = pps;
+      const int ns = cdiv(p.M, pps);
+      dim3 g2((unsigned)cdiv(p.Ktot, 128), (unsigned)cdiv(p.Cout, 128), (unsigned)ns);
+      hipLaunchKernelGGL(conv_wgrad_bf16s_kernel, g2, dim3(WTHR), 0, st, p);
+      MUNIT_CHECK_LAUNCH("conv_wgrad_bf16s");
+      const long long n = (long long)p.Cout * p.Ktot;
+      const int blocks = (int)std::min<long long>((n + p.Cout + 255) / 256, 4096);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, dw, n, p.bias_slab, db, p.Cout,
+                         ns, beta, beta_b);
+      MUNIT_CHECK_LAUNCH("slab_reduce");
+      return MUNIT_OK;
     }
     if (p.x_bf16 && p.dy_bf16) {        // trunk layers: bf16 MFMA (operands are already bf16 values)
       if (pl.bc == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, true, true, 1, true, true>), grid, dim3(WTHR), 0, st, p);

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/${TAG}_trace
 if [ "$2" != "multi" ]; then export MUNIT_NO_SIDE_STREAM=1 MUNIT_NO_BRANCH_STREAMS=1; fi
 export TMPDIR=/tmp
 cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-modes > $ROOT/gpurun_out/${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-modes $BENCH_ARGS > $ROOT/gpurun_out/${TAG}_bench.log 2>&1
 TRACE=$(find $OUT -name "*kernel_trace.csv" | head -1)
 STATS=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp $STATS $ROOT/gpurun_out/${TAG}_kernel_stats.csv

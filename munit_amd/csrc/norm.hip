@@ -83,49 +83,57 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const T* __restrict__ x, d
   }
 }
 
-// y = act((x-mean)*rstd*w + b) + residual ; writes stats[b][c] = (mean, rstd) from split 0
+// Folds the split partials ONCE per (sample, channel): stats[b][c] = (mean, rstd) for the backward and
+// coef[b][2][C] = (scale, shift) of y = x * scale + shift for the apply kernel.  (Every apply block used to repeat this
+// fold in its prologue -- nsplit * 2 * C doubles per block, as many bytes from L2 as the tensor it then streamed.)
+template <typename T>
+__global__ __launch_bounds__(NT) void in_finalize_kernel(const T* __restrict__ x, const double* __restrict__ partial,
+                                                         float* __restrict__ stats, float* __restrict__ coef, int B,
+                                                         int HW, int C, int nsplit, const float* __restrict__ adain,
+                                                         int ad_ld, int w_off, int b_off, float eps) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+    s1 += o[c];
+    s2 += o[C + c];
+  }
+  const double inv_n = 1.0 / (double)HW;
+  const double d = s1 * inv_n;
+  const float mean = (float)((double)ld1(x + (long long)b * HW * C + c) + d);   // pivot = first pixel of the plane
+  double var = s2 * inv_n - d * d;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float w = 1.f, bb = 0.f;
+  if (adain != nullptr) {
+    w = adain[(long long)b * ad_ld + w_off + c];
+    bb = adain[(long long)b * ad_ld + b_off + c];
+  }
+  stats[(long long)i * 2] = mean;
+  stats[(long long)i * 2 + 1] = rstd;
+  coef[((long long)b * 2) * C + c] = rstd * w;
+  coef[((long long)b * 2 + 1) * C + c] = bb - mean * rstd * w;
+}
+
+// y = act(x * scale + shift) + residual
 template <typename T>
 __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                      const double* __restrict__ partial, float* __restrict__ stats,
-                                                      int HW, int C, int nsplit, const float* __restrict__ adain,
-                                                      int ad_ld, int w_off, int b_off,
-                                                      const T* __restrict__ residual, int relu, float eps) {
+                                                      const float* __restrict__ coef, int HW, int C, int nsplit,
+                                                      const T* __restrict__ residual, int relu) {
   extern __shared__ float sm[];  // scale[C], shift[C]
   float* scale = sm;
   float* shift = sm + C;
   const int b = blockIdx.y, sp = blockIdx.x;
-  const T* xb = x + (long long)b * HW * C;
-  for (int c = threadIdx.x; c < C; c += NT) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nsplit; ++k) {
-      const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
-      s1 += o[c];
-      s2 += o[C + c];
-    }
-    const double inv_n = 1.0 / (double)HW;
-    const double d = s1 * inv_n;
-    const float mean = (float)((double)ld1(xb + c) + d);
-    double var = s2 * inv_n - d * d;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float w = 1.f, bb = 0.f;
-    if (adain != nullptr) {
-      w = adain[(long long)b * ad_ld + w_off + c];
-      bb = adain[(long long)b * ad_ld + b_off + c];
-    }
-    scale[c] = rstd * w;
-    shift[c] = bb - mean * rstd * w;
-    if (sp == 0) {
-      stats[((long long)b * C + c) * 2] = mean;
-      stats[((long long)b * C + c) * 2 + 1] = rstd;
-    }
-  }
+  for (int c = threadIdx.x; c < 2 * C; c += NT) sm[c] = coef[(long long)b * 2 * C + c];
   __syncthreads();
   const int CQ = C >> 2;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const long long i0 = (long long)p0 * CQ, i1 = (long long)p1 * CQ;
   const long long base = (long long)b * HW * C;
+#pragma unroll 4
   for (long long i = i0 + threadIdx.x; i < i1; i += NT) {
     const int q = (int)(i % CQ);
     f32x4 v = ld4(x + base + i * 4);
@@ -200,14 +208,41 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const T* __restrict__ 
   }
 }
 
-// dx = rstd*w*(g - mean(g) - xhat*mean(g*xhat)); d_adain weight = sum(g*xhat), bias = sum(g)
+// Backward fold, once per (sample, channel): d_adain weight = sum(g*xhat), bias = sum(g); coef[b][6][C] = mean, rstd,
+// w, b, mean(g), mean(g*xhat) for the apply kernel.
+__global__ __launch_bounds__(NT) void in_bwd_finalize_kernel(const double* __restrict__ partial,
+                                                             const float* __restrict__ stats, float* __restrict__ coef,
+                                                             int B, int HW, int C, int nsplit,
+                                                             const float* __restrict__ adain, float* __restrict__ d_adain,
+                                                             int ad_ld, int w_off, int b_off) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+    a1 += o[c];
+    a2 += o[C + c];
+  }
+  if (d_adain != nullptr) {
+    d_adain[(long long)b * ad_ld + w_off + c] = (float)a2;
+    d_adain[(long long)b * ad_ld + b_off + c] = (float)a1;
+  }
+  const double inv_n = 1.0 / (double)HW;
+  float* o = coef + (long long)b * 6 * C + c;
+  o[0] = stats[(long long)i * 2];
+  o[C] = stats[(long long)i * 2 + 1];
+  o[2 * C] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
+  o[3 * C] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
+  o[4 * C] = (float)(a1 * inv_n);
+  o[5 * C] = (float)(a2 * inv_n);
+}
+
+// dx = rstd*w*(g - mean(g) - xhat*mean(g*xhat))
 template <typename T>
 __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                          const float* __restrict__ stats,
-                                                          const double* __restrict__ partial, T* __restrict__ dx,
-                                                          int HW, int C, int nsplit, const float* __restrict__ adain,
-                                                          float* __restrict__ d_adain, int ad_ld, int w_off, int b_off,
-                                                          int relu) {
+                                                          const float* __restrict__ coef, T* __restrict__ dx,
+                                                          int HW, int C, int nsplit, int relu) {
   extern __shared__ float sm[];  // mean[C], rstd[C], w[C], b[C], a1[C], a2[C]
   float* s_mean = sm;
   float* s_rstd = sm + C;
@@ -216,31 +251,14 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ 
   float* s_a1 = sm + 4 * C;
   float* s_a2 = sm + 5 * C;
   const int b = blockIdx.y, sp = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += NT) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int k = 0; k < nsplit; ++k) {
-      const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
-      a1 += o[c];
-      a2 += o[C + c];
-    }
-    s_mean[c] = stats[((long long)b * C + c) * 2];
-    s_rstd[c] = stats[((long long)b * C + c) * 2 + 1];
-    s_w[c] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
-    s_b[c] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
-    if (sp == 0 && d_adain != nullptr) {
-      d_adain[(long long)b * ad_ld + w_off + c] = (float)a2;
-      d_adain[(long long)b * ad_ld + b_off + c] = (float)a1;
-    }
-    const double inv_n = 1.0 / (double)HW;
-    s_a1[c] = (float)(a1 * inv_n);
-    s_a2[c] = (float)(a2 * inv_n);
-  }
+  for (int c = threadIdx.x; c < 6 * C; c += NT) sm[c] = coef[(long long)b * 6 * C + c];
   __syncthreads();
   const int CQ = C >> 2;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const long long i0 = (long long)p0 * CQ, i1 = (long long)p1 * CQ;
   const long long base = (long long)b * HW * C;
+#pragma unroll 4
   for (long long i = i0 + threadIdx.x; i < i1; i += NT) {
     const int q = (int)(i % CQ);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(s_mean + q * 4);
@@ -489,8 +507,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_param_kernel(const double* __restri
 
 }  // namespace
 
+namespace {
+size_t in_partial_bytes(int B, int C) { return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256); }
+}
+// [split partials (fp64)][per-(sample, channel) coefficients of the apply kernels: 6 floats]
 extern "C" size_t munit_instnorm_workspace_bytes(int B, int HW, int C) {
-  return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256);
+  return in_partial_bytes(B, C) + align_up((size_t)B * 6 * C * sizeof(float), 256);
 }
 
 namespace {
@@ -511,8 +533,12 @@ int instnorm_fwd_t(const T* x, T* y, float* stats, int B, int HW, int C, const f
   hipLaunchKernelGGL(in_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      partial, HW, C, ns);
   MUNIT_CHECK_LAUNCH("in_stats");
-  hipLaunchKernelGGL(in_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, partial,
-                     stats, HW, C, ns, adain, ad_ld, w_off, b_off, residual, relu, eps);
+  float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
+  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(cdiv((long long)B * C, NT)), dim3(NT), 0, st, x, partial, stats, coef, B,
+                     HW, C, ns, adain, ad_ld, w_off, b_off, eps);
+  MUNIT_CHECK_LAUNCH("in_finalize");
+  hipLaunchKernelGGL(in_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, coef, HW, C,
+                     ns, residual, relu);
   MUNIT_CHECK_LAUNCH("in_apply");
   return MUNIT_OK;
 }
@@ -534,8 +560,12 @@ int instnorm_bwd_t(const T* x, const T* dy, const float* stats, T* dx, int B, in
   hipLaunchKernelGGL(in_bwd_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
                      dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_stats");
-  hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, stats,
-                     partial, dx, HW, C, ns, adain, d_adain, ad_ld, w_off, b_off, relu);
+  float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv((long long)B * C, NT)), dim3(NT), 0, st, partial, stats, coef, B, HW,
+                     C, ns, adain, d_adain, ad_ld, w_off, b_off);
+  MUNIT_CHECK_LAUNCH("in_bwd_finalize");
+  hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, coef, dx,
+                     HW, C, ns, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_apply");
   return MUNIT_OK;
 }

@@ -129,7 +129,12 @@ def test_nccl_backend_world1_step(tmp_path):
                        timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out
-    print(out.strip().splitlines()[-1])
+    line = out.strip().splitlines()[-1]
+    print(line)
+    keep = os.path.join(ROOT, "gpurun_out")          # scratch directory of the GPU box runs: keep the measured figure
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "nccl_world1_allreduce.json"), "w") as f:
+            f.write(line + "\n")
 
 
 def test_bench_under_torchrun_one_rank():

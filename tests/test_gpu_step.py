@@ -48,11 +48,11 @@ def test_step_matches_oracle(gs, iters):
 def test_step_unpinned_kinks_stay_within_the_diagnostic_bound():
     """The same comparison without pinning the kinks (each side takes its own ReLU branches): the loose tensors are
     enumerated in the report and may not exceed 10 % of all tensors."""
-    rep = run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", pin_kinks=False)
+    rep = run_step_parity(size=64, batch=1, gen_state=1, iters=1, device="cuda:0", pin_kinks=False)
     print(rep["grad_kinks"])
 
 
-@pytest.mark.parametrize("guided,recon_mask", [(0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("guided,recon_mask", [(0, 1), (1, 0)])
 def test_step_guided0_and_unmasked_cycle_match_oracle(guided, recon_mask):
     """guided: 0 -- translation with the sampled styles s_a / s_b (trainer.py:377-379, 1155-1157): the style target of
     recon_s is then a constant, i.e. the needs_input_grad[1] == False path of the L1 kernel's backward;

@@ -83,6 +83,39 @@ __global__ __launch_bounds__(NT) void in_stats_kernel(const T* __restrict__ x, d
   }
 }
 
+// Sum over the splits of partial[b][split][2][C] for one (sample, channel) per 4 threads: block = 64 channels x 4 split
+// groups (grid: ceil(C/64) x B), every group adds its splits in order, group 0 adds the four group sums in order
+// (deterministic) and returns true with the totals.  A thread per (b, c) walking all 64 splits alone was a 19 us chain of
+// dependent loads, as long as the apply kernel itself.
+__device__ inline bool fold_partials(const double* __restrict__ partial, int B, int C, int nsplit, int& b, int& c,
+                                     double& s1, double& s2) {
+  __shared__ double red[3][64][2];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  b = blockIdx.y;
+  c = blockIdx.x * 64 + cl;
+  s1 = 0.0;
+  s2 = 0.0;
+  if (c < C) {
+    for (int k = g; k < nsplit; k += 4) {
+      const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+      s1 += o[c];
+      s2 += o[C + c];
+    }
+  }
+  if (g > 0) {
+    red[g - 1][cl][0] = s1;
+    red[g - 1][cl][1] = s2;
+  }
+  __syncthreads();
+  if (g > 0 || c >= C) return false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    s1 += red[j][cl][0];
+    s2 += red[j][cl][1];
+  }
+  return true;
+}
+
 // Folds the split partials ONCE per (sample, channel): stats[b][c] = (mean, rstd) for the backward and
 // coef[b][2][C] = (scale, shift) of y = x * scale + shift for the apply kernel.  (Every apply block used to repeat this
 // fold in its prologue -- nsplit * 2 * C doubles per block, as many bytes from L2 as the tensor it then streamed.)
@@ -91,15 +124,10 @@ __global__ __launch_bounds__(NT) void in_finalize_kernel(const T* __restrict__ x
                                                          float* __restrict__ stats, float* __restrict__ coef, int B,
                                                          int HW, int C, int nsplit, const float* __restrict__ adain,
                                                          int ad_ld, int w_off, int b_off, float eps) {
-  const int i = blockIdx.x * NT + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
-    s1 += o[c];
-    s2 += o[C + c];
-  }
+  double s1, s2;
+  int b, c;
+  if (!fold_partials(partial, B, C, nsplit, b, c, s1, s2)) return;
+  const int i = b * C + c;
   const double inv_n = 1.0 / (double)HW;
   const double d = s1 * inv_n;
   const float mean = (float)((double)ld1(x + (long long)b * HW * C + c) + d);   // pivot = first pixel of the plane
@@ -215,15 +243,10 @@ __global__ __launch_bounds__(NT) void in_bwd_finalize_kernel(const double* __res
                                                              int B, int HW, int C, int nsplit,
                                                              const float* __restrict__ adain, float* __restrict__ d_adain,
                                                              int ad_ld, int w_off, int b_off) {
-  const int i = blockIdx.x * NT + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  double a1 = 0.0, a2 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
-    a1 += o[c];
-    a2 += o[C + c];
-  }
+  double a1, a2;
+  int b, c;
+  if (!fold_partials(partial, B, C, nsplit, b, c, a1, a2)) return;
+  const int i = b * C + c;
   if (d_adain != nullptr) {
     d_adain[(long long)b * ad_ld + w_off + c] = (float)a2;
     d_adain[(long long)b * ad_ld + b_off + c] = (float)a1;
@@ -534,7 +557,7 @@ int instnorm_fwd_t(const T* x, T* y, float* stats, int B, int HW, int C, const f
                      partial, HW, C, ns);
   MUNIT_CHECK_LAUNCH("in_stats");
   float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
-  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(cdiv((long long)B * C, NT)), dim3(NT), 0, st, x, partial, stats, coef, B,
+  hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(cdiv(C, 64), B), dim3(NT), 0, st, x, partial, stats, coef, B,
                      HW, C, ns, adain, ad_ld, w_off, b_off, eps);
   MUNIT_CHECK_LAUNCH("in_finalize");
   hipLaunchKernelGGL(in_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)2 * C * sizeof(float), st, x, y, coef, HW, C,
@@ -561,7 +584,7 @@ int instnorm_bwd_t(const T* x, const T* dy, const float* stats, T* dx, int B, in
                      dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
   MUNIT_CHECK_LAUNCH("in_bwd_stats");
   float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
-  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv((long long)B * C, NT)), dim3(NT), 0, st, partial, stats, coef, B, HW,
+  hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv(C, 64), B), dim3(NT), 0, st, partial, stats, coef, B, HW,
                      C, ns, adain, d_adain, ad_ld, w_off, b_off);
   MUNIT_CHECK_LAUNCH("in_bwd_finalize");
   hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3(ns, B), dim3(NT), (size_t)6 * C * sizeof(float), st, x, dy, coef, dx,

@@ -45,6 +45,8 @@ def get_scheduler(optimizer, hyperparameters, iterations=-1):
         scheduler = lr_scheduler.StepLR(optimizer, step_size=hyperparameters["step_size"],
                                         gamma=hyperparameters["gamma"], last_epoch=iterations)
     else:
+        # the reference RETURNS the exception object here instead of raising it (utils.py:1087-1089); kept, because a
+        # caller written against the reference sees the same value (and the same failure at the first .step())
         return NotImplementedError("learning rate policy [%s] is not implemented", hyperparameters["lr_policy"])
     return scheduler
 

@@ -101,6 +101,95 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward on the matrix pipe (round 2): v_mfma_f32_4x4x1_16B_f32.  A 16x16 MFMA tile would be 13/16 padding with three
+// output channels; the 16-block 4x4x1 form wastes only one row in four: block b (lanes 4b..4b+3) computes the outer
+// product D_b[i][j] += A_b[i] * B_b[j] with i = output channel (row 3 is a zero weight) and j = one of 4 adjacent
+// pixels, and the sixteen blocks take sixteen different k: input channels 4b..4b+3 of the current filter tap, delivered
+// by ONE ds_read_b128 per lane and tap (element t feeds MFMA t).  Lane map verified on the hardware with exact integer
+// data (tools/ubench/mfma4x4.hip): A row i = l%4, B column j = l%4, D[i][j] in register i of lane 4*block + j.  The
+// sixteen partial tiles are summed across blocks with four shuffles at the very end.  Same rate as every fp32 MFMA
+// (64 FLOP/clk/SIMD), exact fp32 FMAs like the VALU kernel it replaces (which reaches 0.15 of that rate).
+// Block: 4 waves, output tile 4 rows x 16 pixels (a wave owns one row = 4 pixel groups), 64 input channels per pass,
+// halo patch of 10 x 22 pixels in LDS with a pixel stride of 80 floats (conflict-free b128 reads across the 16 blocks).
+// ---------------------------------------------------------------------------------------------
+template <typename XT>
+__global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
+  constexpr int K = 7, CO = 3, TW = 16, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PS = 80;
+  __shared__ __attribute__((aligned(16))) float patch[PH * PW * PS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int blk = lane >> 2, j = lane & 3;
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int ow0 = tile_x * TW, oh0 = tile_y * TH;
+  const XT* xb = reinterpret_cast<const XT*>(p.x) + (long long)b * p.H * p.W * p.Cin;
+  const float* __restrict__ wg = p.w;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wi = j < CO ? j : 0;             // weight row of this lane (row 3 multiplies by zero)
+  const float wmask = j < CO ? 1.f : 0.f;
+
+  for (int ch0 = 0; ch0 < p.Cin; ch0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < PH * PW * 16; e += 256) {
+      const int c4 = e & 15, pix = e >> 4;
+      const int pr = pix / PW, pc = pix - pr * PW;
+      const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
+      const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ih >= 0 && iw >= 0) v = ld4(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(&patch[pix * PS + c4 * 4]) = v;
+    }
+    __syncthreads();
+    const float* wl = wg + (long long)wi * K * K * p.Cin + ch0 + 4 * blk;   // + tap * Cin
+    f32x4 wf = *reinterpret_cast<const f32x4*>(wl) * wmask;
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const int tap = kh * K + kw;
+        const int nxt = tap + 1 < K * K ? tap + 1 : tap;
+        const f32x4 wn = *reinterpret_cast<const f32x4*>(wl + (long long)nxt * p.Cin) * wmask;   // next tap in flight
+        f32x4 xf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          xf[g] = *reinterpret_cast<const f32x4*>(&patch[((ty + kh) * PW + 4 * g + j + kw) * PS + 4 * blk]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[t], xf[g][t], acc[g], 0, 0, 0);
+        wf = wn;
+      }
+    }
+  }
+  // sum the sixteen blocks (lane bits 2..5); lanes 0..3 then hold pixel j of every group
+  const int oh = oh0 + ty;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      float s = acc[g][c];
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      v[c] = s;
+    }
+    const int ow = ow0 + 4 * g + j;
+    if (blk == 0 && oh < p.Ho && ow < p.Wo) {
+      float* yo = p.y + (((long long)b * p.Ho + oh) * p.Wo + ow) * CO;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) yo[c] = apply_act(v[c] + (p.bias != nullptr ? p.bias[c] : 0.f), p.act, p.slope);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight: channel per lane; unit = (b, band of rows_per_unit output rows, kh, channel group)
 // ---------------------------------------------------------------------------------------------
 template <int CO, int K, typename XT>
@@ -218,6 +307,14 @@ int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, con
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo;
   p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT; p.act = d->act; p.slope = d->slope;
+  if (d->Cin % 64 == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_HEAD_MFMA")) {
+    p.tiles_x = cdiv(Wo, 16); p.tiles_y = cdiv(Ho, 4);
+    const long long nb = (long long)d->B * p.tiles_x * p.tiles_y;
+    if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_head_mfma_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_head_mfma_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p);
+    MUNIT_CHECK_LAUNCH("conv_head_mfma");
+    return MUNIT_OK;
+  }
   p.tiles_x = cdiv(Wo, 64); p.tiles_y = cdiv(Ho, 4);
   const long long blocks = (long long)d->B * p.tiles_x * p.tiles_y;
   if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_patch_fwd_kernel<3, 7, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, p);

@@ -48,6 +48,9 @@ CONV_CASES = [
     (64, 64, 5, 1, 2, "reflect", 0, "none", 2, 7, 9),       # pad 2: two mirrored rows per edge
     (32, 64, 7, 1, 3, "reflect", 0, "none", 1, 10, 13),     # pad 3
     (64, 64, 3, 1, 1, "reflect", 0, "none", 1, 3, 3),       # H = 3: row 1 mirrors both ways -> register-path fallback
+    # 3-channel head on the 4x4x1 MFMA kernel: ragged tile edges, two 64-channel passes, zero padding
+    (64, 3, 7, 1, 3, "reflect", 0, "tanh", 1, 9, 37),
+    (128, 3, 7, 1, 3, "zero", 0, "none", 2, 8, 20),
 ]
 
 

@@ -110,12 +110,21 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
 // sixteen partial tiles are summed across blocks with four shuffles at the very end.  Same rate as every fp32 MFMA
 // (64 FLOP/clk/SIMD), exact fp32 FMAs like the VALU kernel it replaces (which reaches 0.15 of that rate).
 // Block: 4 waves, output tile 4 rows x 16 pixels (a wave owns one row = 4 pixel groups), 64 input channels per pass,
-// halo patch of 10 x 22 pixels in LDS with a pixel stride of 80 floats (conflict-free b128 reads across the 16 blocks).
+// halo patch of 10 x 22 pixels in LDS, 256 bytes per pixel with the 16-byte chunk c of pixel q stored at position
+// c ^ 4*(q&3) (the four pixels of a group then hit four different bank quads for every block: conflict-free b128 reads).
+// fp32 input: the patch is filled by global_load_lds_dwordx4 (one wave instruction = 4 pixels, every lane fetches the
+// chunk that belongs at its landing spot; padding taps read a zero page): all 14 fills of a wave are in flight at once.
+// The thread-per-chunk register loop it replaces waited for every load in turn (~19 us per tile, 6x the MFMA time).
+// bf16 input is widened in registers, with the loads of a thread issued together.
 // ---------------------------------------------------------------------------------------------
+__device__ const float munit_head_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <typename XT>
 __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
-  constexpr int K = 7, CO = 3, TW = 16, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PS = 80;
-  __shared__ __attribute__((aligned(16))) float patch[PH * PW * PS];
+  constexpr int K = 7, CO = 3, TW = 16, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PS = 64;
+  constexpr int NPIX = PH * PW;                       // 220 = 55 groups of 4 pixels
+  static_assert(NPIX % 4 == 0, "patch fills go four pixels at a time");
+  __shared__ __attribute__((aligned(16))) float patch[NPIX * PS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int blk = lane >> 2, j = lane & 3;
@@ -135,14 +144,48 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
 
   for (int ch0 = 0; ch0 < p.Cin; ch0 += 64) {
     __syncthreads();
-    for (int e = tid; e < PH * PW * 16; e += 256) {
-      const int c4 = e & 15, pix = e >> 4;
-      const int pr = pix / PW, pc = pix - pr * PW;
-      const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
-      const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ih >= 0 && iw >= 0) v = ld4(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
-      *reinterpret_cast<f32x4*>(&patch[pix * PS + c4 * 4]) = v;
+    {
+      // wave w fills pixel groups w, w+4, ...: lane l -> pixel 4*grp + (l>>4), landing position l&15, chunk (l&15) ^ 4*(l>>4)
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int sub = lane >> 4, c4 = (lane & 15) ^ (4 * sub);
+      constexpr int NG = NPIX / 4, PER = (NG + 3) / 4;
+      if constexpr (sizeof(XT) == 4) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+          const int grp = wv + 4 * it;
+          if (grp < NG) {
+            const int pix = 4 * grp + sub;
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
+            const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
+            const void* g = (ih >= 0 && iw >= 0) ? (const void*)(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4)
+                                                 : (const void*)munit_head_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(patch + grp * 4 * PS), 16, 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        f32x4 stage[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+          const int grp = wv + 4 * it;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (grp < NG) {
+            const int pix = 4 * grp + sub;
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int ih = map_coord(oh0 + pr - p.pad, p.H, p.reflect);
+            const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
+            if (ih >= 0 && iw >= 0) v = ld4(xb + ((long long)ih * p.W + iw) * p.Cin + ch0 + c4 * 4);
+          }
+          stage[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+          const int grp = wv + 4 * it;
+          if (grp < NG) *reinterpret_cast<f32x4*>(&patch[grp * 4 * PS + lane * 4]) = stage[it];
+        }
+      }
     }
     __syncthreads();
     const float* wl = wg + (long long)wi * K * K * p.Cin + ch0 + 4 * blk;   // + tap * Cin
@@ -157,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
         f32x4 xf[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          xf[g] = *reinterpret_cast<const f32x4*>(&patch[((ty + kh) * PW + 4 * g + j + kw) * PS + 4 * blk]);
+        {
+          const int q = (ty + kh) * PW + 4 * g + j + kw;     // patch pixel; its chunk c sits at position c ^ 4*(q&3)
+          xf[g] = *reinterpret_cast<const f32x4*>(&patch[q * PS + 4 * (blk ^ (4 * (q & 3)))]);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -189,27 +189,32 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
     }
     __syncthreads();
     const float* wl = wg + (long long)wi * K * K * p.Cin + ch0 + 4 * blk;   // + tap * Cin
-    f32x4 wf = *reinterpret_cast<const f32x4*>(wl) * wmask;
+    // weights: one filter row (7 taps) per trip, the next row in flight meanwhile -- a single-tap prefetch distance
+    // (128 cycles of MFMAs) does not cover an L2 hit, and made every tap wait for its weights
+    f32x4 wrow[K], wnext[K];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) wrow[kw] = *reinterpret_cast<const f32x4*>(wl + (long long)kw * p.Cin) * wmask;
 #pragma unroll 1
     for (int kh = 0; kh < K; ++kh) {
+      const int khn = kh + 1 < K ? kh + 1 : kh;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw)
+        wnext[kw] = *reinterpret_cast<const f32x4*>(wl + (long long)(khn * K + kw) * p.Cin) * wmask;
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
-        const int tap = kh * K + kw;
-        const int nxt = tap + 1 < K * K ? tap + 1 : tap;
-        const f32x4 wn = *reinterpret_cast<const f32x4*>(wl + (long long)nxt * p.Cin) * wmask;   // next tap in flight
         f32x4 xf[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-        {
+        for (int g = 0; g < 4; ++g) {
           const int q = (ty + kh) * PW + 4 * g + j + kw;     // patch pixel; its chunk c sits at position c ^ 4*(q&3)
           xf[g] = *reinterpret_cast<const f32x4*>(&patch[q * PS + 4 * (blk ^ (4 * (q & 3)))]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[t], xf[g][t], acc[g], 0, 0, 0);
-        wf = wn;
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wrow[kw][t], xf[g][t], acc[g], 0, 0, 0);
       }
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) wrow[kw] = wnext[kw];
     }
   }
   // sum the sixteen blocks (lane bits 2..5); lanes 0..3 then hold pixel j of every group

@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void conv_patch_fwd_kernel(SmallParams p) {
 // data (tools/ubench/mfma4x4.hip): A row i = l%4, B column j = l%4, D[i][j] in register i of lane 4*block + j.  The
 // sixteen partial tiles are summed across blocks with four shuffles at the very end.  Same rate as every fp32 MFMA
 // (64 FLOP/clk/SIMD), exact fp32 FMAs like the VALU kernel it replaces (which reaches 0.15 of that rate).
-// Block: 4 waves, output tile 4 rows x 16 pixels (a wave owns one row = 4 pixel groups), 64 input channels per pass,
-// halo patch of 10 x 22 pixels in LDS, 256 bytes per pixel with the 16-byte chunk c of pixel q stored at position
+// Block: 4 waves, output tile 8 rows x 16 pixels (a wave owns rows ty and ty + 4 = 8 pixel groups), 64 input channels
+// per pass, halo patch of 14 x 22 pixels in LDS (77 KiB: two blocks per CU; the halo makes the kernel read 2.4x its
+// input, which is what bounds it -- a 4-row tile read 3.4x and ran no faster on a 3x shorter MFMA stream), 256 bytes per pixel with the 16-byte chunk c of pixel q stored at position
 // c ^ 4*(q&3) (the four pixels of a group then hit four different bank quads for every block: conflict-free b128 reads).
 // fp32 input: the patch is filled by global_load_lds_dwordx4 (one wave instruction = 4 pixels, every lane fetches the
 // chunk that belongs at its landing spot; padding taps read a zero page): all 14 fills of a wave are in flight at once.
@@ -121,7 +122,8 @@ __device__ const float munit_head_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <typename XT>
 __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
-  constexpr int K = 7, CO = 3, TW = 16, TH = 4, PW = TW + K - 1, PH = TH + K - 1, PS = 64;
+  constexpr int K = 7, CO = 3, TW = 16, TH = 8, PW = TW + K - 1, PH = TH + K - 1, PS = 64;
+  constexpr int NG_W = 2 * (TW / 4);                  // pixel groups per wave: rows ty and ty + 4, four groups each
   constexpr int NPIX = PH * PW;                       // 220 = 55 groups of 4 pixels
   static_assert(NPIX % 4 == 0, "patch fills go four pixels at a time");
   __shared__ __attribute__((aligned(16))) float patch[NPIX * PS];
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
   const XT* xb = reinterpret_cast<const XT*>(p.x) + (long long)b * p.H * p.W * p.Cin;
   const float* __restrict__ wg = p.w;
 
-  f32x4 acc[4];
+  f32x4 acc[NG_W];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < NG_W; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wi = j < CO ? j : 0;             // weight row of this lane (row 3 multiplies by zero)
   const float wmask = j < CO ? 1.f : 0.f;
 
@@ -202,25 +204,26 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
         wnext[kw] = *reinterpret_cast<const f32x4*>(wl + (long long)(khn * K + kw) * p.Cin) * wmask;
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
-        f32x4 xf[4];
+        f32x4 xf[NG_W];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int q = (ty + kh) * PW + 4 * g + j + kw;     // patch pixel; its chunk c sits at position c ^ 4*(q&3)
+        for (int g = 0; g < NG_W; ++g) {
+          const int q = (ty + 4 * (g >> 2) + kh) * PW + 4 * (g & 3) + j + kw;   // patch pixel; chunk c at position c ^ 4*(q&3)
           xf[g] = *reinterpret_cast<const f32x4*>(&patch[q * PS + 4 * (blk ^ (4 * (q & 3)))]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wrow[kw][t], xf[g][t], acc[g], 0, 0, 0);
+          for (int g = 0; g < NG_W; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wrow[kw][t], xf[g][t], acc[g], 0, 0, 0);
       }
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) wrow[kw] = wnext[kw];
     }
   }
   // sum the sixteen blocks (lane bits 2..5); lanes 0..3 then hold pixel j of every group
-  const int oh = oh0 + ty;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < NG_W; ++g) {
+    const int oh = oh0 + ty + 4 * (g >> 2);
     float v[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
       s += __shfl_xor(s, 32, 64);
       v[c] = s;
     }
-    const int ow = ow0 + 4 * g + j;
+    const int ow = ow0 + 4 * (g & 3) + j;
     if (blk == 0 && oh < p.Ho && ow < p.Wo) {
       float* yo = p.y + (((long long)b * p.Ho + oh) * p.Wo + ow) * CO;
 #pragma unroll
@@ -359,7 +362,7 @@ int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, con
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo;
   p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT; p.act = d->act; p.slope = d->slope;
   if (d->Cin % 64 == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_HEAD_MFMA")) {
-    p.tiles_x = cdiv(Wo, 16); p.tiles_y = cdiv(Ho, 4);
+    p.tiles_x = cdiv(Wo, 16); p.tiles_y = cdiv(Ho, 8);
     const long long nb = (long long)d->B * p.tiles_x * p.tiles_y;
     if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_head_mfma_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv_head_mfma_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p);

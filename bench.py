@@ -341,6 +341,8 @@ def main():
             tot_ms = sum(t for _, t in sel)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic_bytes()
+            if (args.size, args.batch) != (256, 8):
+                traffic, traffic_src = None, "the committed PMC summary is of the 256x256 batch-8 workload"
             sec = ms_per_step * 1e-3
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

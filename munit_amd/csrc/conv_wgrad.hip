@@ -707,7 +707,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m_begin + 32 * i + r;
-    decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, 0, px_b[i], px_oh[i], px_ow[i]);
+    decode_pixel(m < p.M ? m : 0, p.Ho, p.Wo, p.frame, px_b[i], px_oh[i], px_ow[i]);
     dp_off[i] = px_b[i] * (int)p.dy_sb + px_oh[i] * (int)p.dy_sh + px_ow[i] * p.dy_sw + (int)p.dy_off + d_col;
   }
   const int hw = p.Ho * p.Wo;
@@ -735,6 +735,13 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
                                        (__attribute__((address_space(3))) void*)(sb + i * IMG + 1024 * w), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
                                        (__attribute__((address_space(3))) void*)(sb + (2 + i) * IMG + 1024 * w), 16, 0, 0);
+      if (p.frame) {
+        // frame enumeration (the 2-pixel border of the sub-pixel form): rows are not a raster walk, decode the next one
+        const int mn = m + BS_WP;
+        decode_pixel(mn < p.M ? mn : 0, p.Ho, p.Wo, 1, px_b[i], px_oh[i], px_ow[i]);
+        dp_off[i] = px_b[i] * (int)p.dy_sb + px_oh[i] * (int)p.dy_sh + px_ow[i] * p.dy_sw + (int)p.dy_off + d_col;
+        continue;
+      }
       int ow = px_ow[i] + step_w;
       const bool cw = ow >= p.Wo;
       ow -= cw ? p.Wo : 0;
@@ -967,13 +974,15 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
   // FAST loader: 32-bit byte offsets and 24-bit multiplies (see the kernel)
   const long long xb = (long long)p.B * p.H * p.W * p.Cin * (p.x_bf16 ? 2 : 4), db_ = (long long)p.B * p.dy_sb * (p.dy_bf16 ? 2 : 4);
   const bool any_bf16 = p.x_bf16 || p.dy_bf16;
-  const bool fast = aligned && (p.Cout % 4 == 0) && !p.frame && xb < (1ll << 31) && db_ < (1ll << 31) &&
-                    (long long)p.B * p.H * p.W < (1ll << 23) && (any_bf16 || !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD"));
+  const bool fast_any = aligned && (p.Cout % 4 == 0) && xb < (1ll << 31) && db_ < (1ll << 31) &&
+                        (long long)p.B * p.H * p.W < (1ll << 23) && (any_bf16 || !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FAST_WGRAD"));
+  const bool fast = fast_any && !p.frame;
   p.x_bytes = fast ? (unsigned)xb : 0u;
   p.dy_bytes = fast ? (unsigned)db_ : 0u;
   if (any_bf16) {
     // bf16 storage: only the FAST register loader reads bf16 tensors
-    if (!fast) {
+    const bool dma_ok = p.x_bf16 && p.dy_bf16 && p.Cin % 128 == 0 && p.Cout % 8 == 0 && p.Ho + p.Wo <= DMA_MAX_HW;
+    if (!fast && !(fast_any && dma_ok)) {   // (the frame enumeration exists in the direct-to-LDS kernel only)
       munit_set_error("conv2d_wgrad: bf16 tensors need Cin %% 4 == 0, Cout %% 4 == 0 and tensors below 2 GiB");
       return MUNIT_ERR_ARG;
     }
@@ -1050,8 +1059,11 @@ void plan_cin3(const munit_conv_desc* d, int Ho, int Wo, Cin3Plan* cp) {
 }
 
 bool subpixel_wgrad_ok(const munit_conv_desc* d) {
-  // (bf16 tensors take the direct 25-tap form: its frame launches use the generic loader, which reads fp32 only)
-  return d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
+  // bf16 tensors: only where the direct-to-LDS bf16 kernel applies (it alone enumerates the frame on bf16 data)
+  const bool f32 = d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32;
+  const bool b16 = d->in_dtype == MUNIT_DTYPE_BF16 && d->out_dtype == MUNIT_DTYPE_BF16 && d->Cin % 128 == 0 &&
+                   d->Cout % 8 == 0 && 2 * (d->H + d->W) <= DMA_MAX_HW && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA");
+  return (f32 || b16) && d->upsample == 1 && d->KH == 5 && d->KW == 5 && d->pad == 2 && d->stride == 1 &&
          d->pad_mode == MUNIT_PAD_REFLECT && d->Cin % 4 == 0 && d->H >= 3 && d->W >= 3 &&
          !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SUBPIXEL");
 }

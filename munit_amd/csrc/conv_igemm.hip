@@ -54,6 +54,7 @@ struct IgemmParams {
   int patch; // ROLE 2: at most two padded positions per axis fold onto a pixel -> direct-to-LDS tiles + LDS patch
   int out_bf16;   // the epilogue rounds to bf16 (bias + activation applied in fp32 first)
   int bf16s;      // x and w are bf16 in HBM (see x): direct-to-LDS tiles of 64 bf16 per row, v_mfma_f32_16x16x32_bf16
+  int cin4;       // x is the 4-channel re-layout of a 3-channel tensor, w the matching padded image (CT == 5)
 };
 
 // sum of packed bf16 octets (the LDS patch of the bf16-storage backward-data): fp32 adds, one rounding
@@ -161,9 +162,17 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // instead of 32 floats, which is the only thing that changes for the direct-to-LDS loader (the host hands it the
   // tensors as float tensors with Cin/2 channels), the fragment ds_read_b128 now holds the 8 consecutive k of one
   // v_mfma_f32_16x16x32_bf16 operand, and one MFMA replaces four.
+  // CT == 5: fp32 direct-to-LDS tiles for layers with THREE input channels (the 7x7 first layers, the 4x4 first layers of
+  // the discriminators, the backward-data of the image head).  The host re-lays the image with a zero 4th channel, so
+  // a 128-byte tile row is 8 filter taps x 4 channels and every lane's 16 bytes are ONE pixel of ONE tap: the lane
+  // derives its tap from its chunk index and fetches that pixel -- no scalar per-element gather (the ALIGNED == false
+  // kernel needed 12 loads and ~200 VALU per row and K-tile for the same bytes) -- against a weight image padded the
+  // same way ([Cout][8 taps x 4] per K-tile, zero beyond the last tap).
   constexpr bool BF16 = CT == 1 || CT == 2;
-  constexpr bool DMA = CT == 3 || CT == 4;
+  constexpr bool DMA = CT == 3 || CT == 4 || CT == 5;
   constexpr bool BF16S = CT == 4;
+  constexpr bool CIN4 = CT == 5;
+  static_assert(!CIN4 || ROLE != 2, "4-channel taps: single-gather roles only");
   static_assert(!DMA || (ALIGNED && NWAVES == 8), "direct-to-LDS loads: aligned variants only");
   // ROLE 2 with CT == 3 ("fold by LDS patch"): layers whose pad adjoint folds at most two padded positions per axis onto
   // a source pixel (no up-sampling; reflect pad 1 of the 3x3 resblock convs).  The primary position of every row is a
@@ -433,11 +442,24 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   const int dma_col = ((c4 ^ ((r0 >> 1) & 7)) * 4);   // global chunk (floats) this lane fetches; RSTEP % 16 == 0
   auto dma_tile = [&](int kt, int buf) {
     if constexpr (DMA) {
-      if (c0 == 0 || kt == kt_begin) tap_setup();
+      if constexpr (!CIN4) {
+        if (c0 == 0 || kt == kt_begin) tap_setup();
+      }
       const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;
+      // CIN4: this lane's tap inside the K-tile (8 taps of 4 channels) and its position in the filter
+      const int tap4 = kt * 8 + (dma_col >> 2);
+      const int kh4 = tap4 / p.KW, kw4 = tap4 - kh4 * p.KW;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        const float* g = aoff[i] >= 0 ? xg + (long long)aoff[i] + c0 + dma_col : munit_zero_page + dma_col;
+        const float* g;
+        if constexpr (CIN4) {
+          const int ih = src_coord(a_ih0[i] + kh4, p.Hu, p.ups, p.reflect);
+          const int iw = src_coord(a_iw0[i] + kw4, p.Wu, p.ups, p.reflect);
+          const bool ok = a_ok[i] && tap4 < p.KH * p.KW && ih >= 0 && iw >= 0;
+          g = ok ? xg + (long long)(a_base[i] + ih * p.W + iw) * 4 : munit_zero_page;
+        } else {
+          g = aoff[i] >= 0 ? xg + (long long)aoff[i] + c0 + dma_col : munit_zero_page + dma_col;
+        }
         float* l = smem + buf * (BM * 32) + (wrow + RSTEP * i) * 32;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -460,10 +482,12 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
-      c0 += BK;
-      if (c0 >= p.Cin) {
-        c0 = 0;
-        if (++kw == p.KW) { kw = 0; ++kh; }
+      if constexpr (!CIN4) {
+        c0 += BK;
+        if (c0 >= p.Cin) {
+          c0 = 0;
+          if (++kw == p.KW) { kw = 0; ++kh; }
+        }
       }
     }
   };
@@ -1003,7 +1027,15 @@ int launch_igemm(const IgemmParams& p, int phases, hipStream_t st, void* slab = 
   }
   dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, (unsigned)q.ksplit);
   dim3 block(NTHR);
-  if (p.bf16s) {
+  if (p.cin4) {
+    if constexpr (ROLE == 2) {
+      munit_set_error("conv_igemm: 4-channel taps are not a folded-backward-data form");
+      return MUNIT_ERR_ARG;
+    } else {
+      if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, true, ROLE, 5>), grid, block, 0, st, q);
+      else hipLaunchKernelGGL((conv_igemm_kernel<128, true, ROLE, 5>), grid, block, 0, st, q);
+    }
+  } else if (p.bf16s) {
     if constexpr (ROLE == 2) {
       if (!p.patch || p.frame) {
         munit_set_error("conv_igemm: bf16-storage folded backward-data exists for the LDS-patch form only");
@@ -1095,6 +1127,46 @@ bool subpixel_ok(const munit_conv_desc* d) {
 }  // namespace
 
 namespace {
+// ---- three input channels on the direct-to-LDS path (CT == 5): 4-channel re-layouts built per call into the workspace
+__global__ void pad3to4_image_kernel(const float* __restrict__ x, f32x4* __restrict__ x4, long long npix) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x)
+    x4[i] = f32x4{x[3 * i], x[3 * i + 1], x[3 * i + 2], 0.f};
+}
+// w [N][taps][3] -> w4 [N][kpad], kpad = taps * 4 rounded up to the 32-wide K-tile, zero channel 3 and zero tail
+__global__ void pad3to4_weight_kernel(const float* __restrict__ w, float* __restrict__ w4, int N, int taps, int kpad) {
+  const long long total = (long long)N * kpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / kpad), k = (int)(i - (long long)n * kpad);
+    const int tap = k >> 2, c = k & 3;
+    w4[i] = (tap < taps && c < 3) ? w[((long long)n * taps + tap) * 3 + c] : 0.f;
+  }
+}
+struct Cin4Plan {
+  int kpad;
+  size_t x4_bytes, w4_bytes;
+};
+// npix pixels of the 3-channel tensor, N GEMM columns, taps filter taps
+Cin4Plan plan_cin4(long long npix, int N, int taps) {
+  Cin4Plan c;
+  c.kpad = (taps * 4 + BK - 1) / BK * BK;
+  c.x4_bytes = align_up((size_t)npix * 4 * sizeof(float), 256);
+  c.w4_bytes = align_up((size_t)N * c.kpad * sizeof(float), 256);
+  return c;
+}
+int build_cin4(const Cin4Plan& c, const float* x3, long long npix, const float* w3, int N, int taps, void* ws, hipStream_t st) {
+  f32x4* x4 = reinterpret_cast<f32x4*>(ws);
+  float* w4 = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + c.x4_bytes);
+  hipLaunchKernelGGL(pad3to4_image_kernel, dim3((unsigned)std::min<long long>((npix + 255) / 256, 8192)), dim3(256), 0, st, x3, x4, npix);
+  MUNIT_CHECK_LAUNCH("pad3to4_image");
+  hipLaunchKernelGGL(pad3to4_weight_kernel, dim3((unsigned)cdiv((long long)N * c.kpad, 256)), dim3(256), 0, st, w3, w4, N, taps, c.kpad);
+  MUNIT_CHECK_LAUNCH("pad3to4_weight");
+  return MUNIT_OK;
+}
+bool cin4_fwd_ok(const munit_conv_desc* d) {
+  return d->Cin == 3 && d->in_dtype == MUNIT_DTYPE_F32 && d->upsample == 0 && d->KH * d->KW <= 64 && d->Cout % 4 == 0 &&
+         NWAVES == 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_CIN4");
+}
+
 // forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
 munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* wp) {
   munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1, 0};
@@ -1116,6 +1188,10 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
   if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16) return img;
+  if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
+    const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
+    return c.x4_bytes + c.w4_bytes;
+  }
   if (subpixel_ok(d))   // split-K slabs of the frame launch (few tiles, 25-tap K)
     return img + splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1);
   return img + splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
@@ -1176,6 +1252,16 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
   p.ps = 1;
   p.bf16s = d->in_dtype == MUNIT_DTYPE_BF16;
   p.out_bf16 = d->out_dtype == MUNIT_DTYPE_BF16;
+  if (cin4_fwd_ok(d)) {
+    const long long npix = (long long)d->B * d->H * d->W;
+    const Cin4Plan c = plan_cin4(npix, d->Cout, d->KH * d->KW);
+    rc = build_cin4(c, reinterpret_cast<const float*>(x), npix, w, d->Cout, d->KH * d->KW, ws, st);
+    if (rc) return rc;
+    p.x = reinterpret_cast<const float*>(ws);
+    p.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + c.x4_bytes);
+    p.Ktot = c.kpad; p.w_row = c.kpad; p.cin4 = 1;
+    return launch_igemm<0>(p, 1, st);
+  }
   if (it.kind == MUNIT_PREP_SUBPIXEL) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
@@ -1233,7 +1319,8 @@ struct DgradPlan {
   bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
   bool bf16s;   // dy (and the weight image) are bf16 in HBM: bf16-storage kernels (direct-to-LDS forms only)
   bool patch;   // folded with at most two padded positions per axis: the LDS-patch form
-  size_t wt_bytes, g_bytes, sk_bytes;
+  bool cin4;    // three output channels (the image head): dy re-laid with a zero 4th channel, direct-to-LDS 4-channel taps
+  size_t wt_bytes, g_bytes, sk_bytes, c4_bytes;
 };
 // number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
 int max_fold_cands(int H, int ups, int P, int reflect) {
@@ -1292,7 +1379,17 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * esz, 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
   if (pl->boxsum) pl->g_bytes = align_up((size_t)d->B * pl->Ho * pl->Wo * d->Cout * sizeof(float), 256);  // S
+  pl->cin4 = false;
+  pl->c4_bytes = 0;
   if (pl->bf16s) {
+    pl->sk_bytes = 0;
+    return MUNIT_OK;
+  }
+  if (!pl->direct && !pl->folded && !pl->small && pl->ps == 1 && d->Cout == 3 && d->out_dtype == MUNIT_DTYPE_F32 &&
+      pl->TH * pl->TW <= 64 && d->Cin % 4 == 0 && NWAVES == 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_CIN4")) {
+    const Cin4Plan c = plan_cin4((long long)d->B * pl->Ho * pl->Wo, d->Cin, pl->TH * pl->TW);
+    pl->cin4 = true;
+    pl->c4_bytes = c.x4_bytes + c.w4_bytes;
     pl->sk_bytes = 0;
     return MUNIT_OK;
   }
@@ -1310,7 +1407,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
 extern "C" size_t munit_conv2d_dgrad_workspace_bytes(const munit_conv_desc* d) {
   DgradPlan pl;
   if (plan_dgrad(d, &pl)) return 0;
-  return pl.wt_bytes + pl.g_bytes + pl.sk_bytes;
+  return pl.wt_bytes + pl.g_bytes + pl.sk_bytes + pl.c4_bytes;
 }
 
 extern "C" int munit_conv2d_dgrad(const munit_conv_desc* d, const void* dy, const float* w,
@@ -1340,8 +1437,8 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
   int rc = plan_dgrad(d, &pl);
   if (rc) return rc;
   MUNIT_CHECK_ARG(dy_ && (w || wp) && dx_ && ws, "conv2d_dgrad: null pointer");
-  if (ws_bytes < pl.wt_bytes + pl.g_bytes + pl.sk_bytes) {
-    munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes + pl.sk_bytes);
+  if (ws_bytes < pl.wt_bytes + pl.g_bytes + pl.sk_bytes + pl.c4_bytes) {
+    munit_set_error("conv2d_dgrad: workspace %zu < %zu", ws_bytes, pl.wt_bytes + pl.g_bytes + pl.sk_bytes + pl.c4_bytes);
     return MUNIT_ERR_WORKSPACE;
   }
   // element types: dy = d->out_dtype, dx / add / g = d->in_dtype.  The fp32 names below keep the fp32 code readable; in
@@ -1456,7 +1553,20 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
   p.y_phase_row = (long long)pl.Wq * d->Cin;
   p.y_phase_col = d->Cin;
   p.bf16s = pl.bf16s; p.out_bf16 = dx_bf16;
-  rc = launch_igemm<1>(p, pl.ps * pl.ps, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
+  if (pl.cin4) {
+    // image head: dy has three channels -> 4-channel re-layout of dy and of the transposed weights, direct-to-LDS taps
+    char* c4 = reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes;
+    const long long npix = (long long)d->B * pl.Ho * pl.Wo;
+    const Cin4Plan c = plan_cin4(npix, d->Cin, pl.TH * pl.TW);
+    rc = build_cin4(c, dy, npix, wt, d->Cin, pl.TH * pl.TW, c4, st);
+    if (rc) return rc;
+    p.x = reinterpret_cast<const float*>(c4);
+    p.w = reinterpret_cast<const float*>(c4 + c.x4_bytes);
+    p.Ktot = c.kpad; p.w_row = c.kpad; p.cin4 = 1;
+    rc = launch_igemm<1>(p, 1, st);
+  } else {
+    rc = launch_igemm<1>(p, pl.ps * pl.ps, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
+  }
   if (rc) return rc;
   if (!direct) {
     const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
@@ -1530,6 +1640,8 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile
+      return 2.0 * d->Cout * d->B * Ho * Wo * plan_cin4(1, 1, d->KH * d->KW).kpad;
     return cc * d->B * Ho * Wo * d->KH * d->KW;
   }
   DgradPlan pl;
@@ -1537,6 +1649,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (pl.boxsum) return cc * d->B * ((double)(d->H - 4) * (d->W - 4) + 4.0 * d->W + 4.0 * (d->H - 4)) * d->KH * d->KW;
   if (pl.folded) return cc * d->B * d->H * d->W * d->KH * d->KW;
   if (pl.direct) return cc * d->B * Ho * Wo * d->KH * d->KW;
+  if (pl.cin4) return 2.0 * d->Cin * d->B * (double)(pl.Ho + pl.TH - 1) * (pl.Wo + pl.TW - 1) * plan_cin4(1, 1, pl.TH * pl.TW).kpad;
   // phase launches over the padded domain (also the 3-channel first layer through the thread-per-pixel kernel)
   return cc * d->B * (double)(pl.Ho + pl.TH - 1) * (pl.Wo + pl.TW - 1) * pl.TH * pl.TW * pl.ps * pl.ps;
 }

@@ -51,6 +51,11 @@ CONV_CASES = [
     # 3-channel head on the 4x4x1 MFMA kernel: ragged tile edges, two 64-channel passes, zero padding
     (64, 3, 7, 1, 3, "reflect", 0, "tanh", 1, 9, 37),
     (128, 3, 7, 1, 3, "zero", 0, "none", 2, 8, 20),
+    # three INPUT channels on the direct-to-LDS 4-channel-tap path: ragged sizes, stride 2, 5x5 (K-tile tail of zero taps)
+    (3, 64, 7, 1, 3, "reflect", 0, "relu", 1, 13, 37),
+    (3, 128, 4, 2, 1, "reflect", 0, "lrelu", 2, 10, 14),
+    (3, 32, 5, 1, 2, "zero", 0, "none", 2, 9, 11),
+    (32, 3, 5, 1, 2, "reflect", 0, "none", 2, 9, 11),        # 3 output channels, not 7x7: backward-data on that path too
 ]
 
 

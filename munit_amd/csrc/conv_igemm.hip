@@ -99,7 +99,6 @@ constexpr int BK = 32;
 #endif
 constexpr int NWAVES = IGEMM_WAVES;   // 8: wave tile 64x32 (BN=128), four waves per SIMD; 4: wave tile 64x64, two per SIMD
 constexpr int NTHR = 64 * NWAVES;
-constexpr int RSTEP = NTHR / 8;       // loader rows covered per pass of the block (8 float4 per 32-wide K row)
 constexpr int LDS_LD = BK + 4;
 
 // Padded/up-sampled coordinates whose gradient folds onto source coordinate i (adjoint of
@@ -195,6 +194,17 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   // LDS operand traffic per FLOP, same exact-f32 fma chain.
   constexpr int MT = WM / 16;                 // 16-row MFMA tiles per wave: 4 or 2
   constexpr int NT = WN / 16;
+  // Direct-to-LDS single-gather fp32 variants: the tile loads of a block can be issued by its first IGEMM_LOADER_WAVES
+  // waves only (default: all 8).  With 4, waves 0-3 spend the head of every K-tile on addresses and load issue while
+  // waves 4-7 -- their partners on the four SIMDs -- start their fragment reads and MFMAs at once, so the two waves of a
+  // SIMD stop meeting the LDS and the matrix pipe in lockstep after every barrier (MI355X_MICROARCH.md, two waves per
+  // SIMD, item 9).  A/B switch: `make alt ALTFLAGS=-DIGEMM_LOADER_WAVES=4`.  Measured (tools/ab_bench.sh, one box): 352 vs
+  // 344 us for the resblock layer, step 161.1 vs 161.0 ms -- no gain, so the default stays 8.
+#ifndef IGEMM_LOADER_WAVES
+#define IGEMM_LOADER_WAVES 8
+#endif
+  constexpr int LW = (CT == 3 && ROLE != 2 && NWAVES == 8) ? IGEMM_LOADER_WAVES : NWAVES;
+  constexpr int RSTEP = 64 * LW / 8;          // loader rows covered per pass (shadows the file-level constant)
   constexpr int AROWS = BM / RSTEP;           // gather rows per loader thread (512 threads x float4 = 64 rows)
   constexpr int BROWS = BN / RSTEP;           // weight rows per loader thread
   // double-buffered A/B tiles: one barrier per K-tile (72 KiB at BN=128: two blocks per CU)
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(NTHR, NWAVES == 8 ? ((CT == 3 && BN == 64) ? 6 : 4)
   const int dma_col = ((c4 ^ ((r0 >> 1) & 7)) * 4);   // global chunk (floats) this lane fetches; RSTEP % 16 == 0
   auto dma_tile = [&](int kt, int buf) {
     if constexpr (DMA) {
+      if (LW < NWAVES && __builtin_amdgcn_readfirstlane(wave) >= LW) return;   // not a loader wave of this variant
       if constexpr (!CIN4) {
         if (c0 == 0 || kt == kt_begin) tap_setup();
       }

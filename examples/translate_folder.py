@@ -35,7 +35,8 @@ def save_image(x, path):
     Image.fromarray(arr).save(path)
 
 
-def main(argv=None):
+def main(argv=None, keep=None):
+    """keep: optional list that receives the translated tensors (x_ab per content image, before the JPEG encoding)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
     ap.add_argument("--checkpoint", default=None, help="gen_XXXXXXXX.pt written by MUNIT_Trainer.save (random weights if omitted)")
@@ -77,6 +78,8 @@ def main(argv=None):
                 save_image((x_a + 1) / 2.0, os.path.join(args.output_folder, "input{:03d}.jpg".format(j)))
             c_a, _ = enc(x_a, 1)
             x_ab = dec(c_a, s_b, 2)
+            if keep is not None:
+                keep.append(x_ab.detach().float().cpu())
             out = os.path.join(args.output_folder, "output{:03d}.jpg".format(j))
             save_image((x_ab + 1) / 2.0, out)
             outs.append(out)

@@ -195,10 +195,27 @@ def test_translate_folder_example_and_sample_fid(tmp_path):
     tr.save(str(tmp_path / "ckpt"), 0)
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import translate_folder
+    kept = []
     outs = translate_folder.main(["--config", str(cfg), "--checkpoint", str(tmp_path / "ckpt" / "gen_00000001.pt"),
                                   "--input-folder", str(tmp_path / "content"), "--style", str(tmp_path / "style.png"),
-                                  "--output-folder", str(tmp_path / "out"), "--save-input"])
+                                  "--output-folder", str(tmp_path / "out"), "--save-input"], keep=kept)
     assert [os.path.basename(o) for o in outs] == ["output000.jpg", "output001.jpg"]
+    # the same harness on the oracle (scripts/test.py:86-129): PIL / torchvision-restated transform of the files, fp64
+    # GenView with the checkpoint's weights -- style from encode(., 2), content from encode(., 1), decode(., ., 2)
+    from oracle import data_oracle as DO
+    from oracle import munit_oracle as O
+    from tests.parity import nerr
+    sd = torch.load(tmp_path / "ckpt" / "gen_00000001.pt", weights_only=True)["2"]
+    gen64 = {k: v.double() for k, v in sd.items() if v.dtype == torch.float32 and "running_" not in k}
+    view = O.GenView(gen64, hp["gen"], True)
+    load = lambda f: DO.transform_image(Image.open(f).convert("RGB"), False, 64, None)[None].double()   # noqa: E731
+    with torch.no_grad():
+        _, s_ref = view.encode(load(tmp_path / "style.png"), 2)
+        for k in range(2):
+            c_ref, _ = view.encode(load(tmp_path / "content" / ("c%d.png" % k)), 1)
+            want = view.decode(c_ref, s_ref, 2)
+            assert tuple(kept[k].shape) == tuple(want.shape)
+            assert nerr(kept[k], want) <= 1e-4, (k, nerr(kept[k], want))
     im = Image.open(outs[0])
     rs_w = int(64 * 90 / 70)                                          # Resize(64): shorter side 64, aspect kept -> 82
     down = lambda n: (n + 2 - 4) // 2 + 1                             # the two 4x4 stride-2 convs, then two x2 up-samplings

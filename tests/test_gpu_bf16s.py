@@ -201,3 +201,27 @@ def test_step_bf16_storage_tracks_fp32_step():
     assert torch.isfinite(gb).all()
     cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
     assert cos > 0.98, cos
+
+
+def test_bf16_storage_two_generators_and_inference():
+    """gen_state 0 (two AdaINGen) in bf16 storage: one update runs with finite losses, and the inference entry points
+    (forward / sample) return fp32 images."""
+    from munit_amd.trainer import MUNIT_Trainer
+    import bench
+    hp = bench.bench_hp(64, 2, gen_state=0)
+    hp["precision"] = "bf16s"
+    hp["display_size"] = 2
+    torch.manual_seed(7)
+    tr = MUNIT_Trainer(hp)
+    tr.to(dev())
+    x_a, x_b, m_a, m_b = (t.to(dev()) for t in bench.make_batch(2, 64))
+    tr.update_learning_rate()
+    tr.dis_update(x_a, x_b, hp)
+    tr.gen_update(x_a, x_b, hp, m_a, m_b)
+    for n in ("loss_gen_total", "loss_dis_total", "loss_gen_recon_c_a", "loss_gen_cycrecon_x_b"):
+        v = float(getattr(tr, n).detach())
+        assert v == v and 0 < v < 1e4, (n, v)
+    x_ab, x_ba = tr.forward(x_a, x_b)
+    outs = tr.sample(x_a, x_b)
+    assert x_ab.dtype == F32 and all(o.dtype == F32 and tuple(o.shape) == (2, 3, 64, 64) for o in outs)
+    assert torch.isfinite(x_ab).all() and torch.isfinite(outs[3]).all()

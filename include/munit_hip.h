@@ -9,12 +9,14 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no torch types.
- *   - All tensor pointers are DEVICE pointers to float32.  Activations are NHWC
- *     ([B][H][W][C], C contiguous) -- the memory image of a torch channels_last tensor.
+ *   - All tensor pointers are DEVICE pointers.  Parameters, their gradients, statistics and loss scalars are float32;
+ *     activations are float32 or -- in the bf16-storage mode, see MUNIT_DTYPE_* -- bfloat16, and then travel as void*.
+ *     Activations are NHWC ([B][H][W][C], C contiguous) -- the memory image of a torch channels_last tensor.
  *     Convolution weights are [Cout][KH][KW][Cin] -- the memory image of a torch OIHW
  *     tensor in channels_last format, so state_dict shapes stay (O, I, KH, KW).
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*); the library
- *     never synchronises, allocates no device memory and keeps no state between calls.
+ *     never synchronises, allocates no device memory and keeps no state between calls
+ *     (munit_stream_wait_stream caches one HIP event per host thread and device).
  *     The caller owns every buffer, including the workspace `ws` (size from the matching
  *     *_workspace_bytes query; must be 256-byte aligned).
  *   - Return value: 0 on success, negative on error; munit_last_error() returns a

@@ -319,13 +319,13 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
     pl = _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, in_dt=_dt(x), out_dt=_dt(dy))
     with _on(x):
         ws = workspace(pl.ws_wgrad, x.device, stream)
+        if (dw is None or (db is None and want_bias)) and stream is not None:
+            raise RuntimeError("munit_amd.conv2d_wgrad_raw: give dw / db when launching on another stream")
         if dw is None:
-            assert stream is None
             dw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32,
                              memory_format=torch.channels_last)
             beta = 0.0
         if db is None and want_bias:
-            assert stream is None
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
         st = _stream() if stream is None else c_void_p(stream.cuda_stream)
         _lib.check(lib.munit_conv2d_wgrad(pl.ref, _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(), st),

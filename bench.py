@@ -63,13 +63,13 @@ PMC_SUMMARY = "profiles/r02_pmc_hbm_mfma.txt"
 
 
 def lib_fingerprint():
-    """sha256 (first 16 hex digits) over the kernel sources the library is built from: ties a committed PMC summary to
-    the code it was collected on (the .so itself is not in git)."""
+    """sha256 (first 16 hex digits) over the kernel sources (munit_amd/csrc/*.hip, *.h): ties a committed PMC summary to
+    the code it was collected on (the .so itself is not in git; the public header holds declarations only)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "munit_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "munit_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "munit_hip.h")]):
+                    glob.glob(os.path.join(ROOT, "munit_amd", "csrc", "*.h"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

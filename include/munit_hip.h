@@ -246,6 +246,14 @@ int munit_weighted_sum(const float* const* terms, const float* w, int n, float* 
 int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
                     double beta2, double eps, double weight_decay, int step, munit_stream_t stream);
 
+/* The same update for a launch that is captured into a hipGraph and replayed (munit_amd/graph.py): the two scalars that
+ * change from step to step -- lr / (1 - beta1^t) and sqrt(1 - beta2^t) -- are read from dyn[0], dyn[1] in DEVICE memory,
+ * which the host refreshes before every replay with the values munit_adam_dynamic_scalars computes (the same double ->
+ * float conversions as munit_adam_step, so the replayed step is bit-identical to the eager one). */
+void munit_adam_dynamic_scalars(double lr, double beta1, double beta2, int step, float* out2 /* host, 2 floats */);
+int munit_adam_step_graph(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2,
+                          double eps, double weight_decay, const float* dyn, munit_stream_t stream);
+
 /* ExtraAdam (scripts/extraadam.py:14-168; selected by `optimizer: extra...`, scripts/trainer.py:41-45,
  * stepped by the *_opt_step methods, trainer.py:252-268: extrapolation on even iterations, step on odd).
  * Every call advances the moments and forms u = -lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).

@@ -739,6 +739,21 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
                                        float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
+def adam_step_graph(p, g, m, v, beta1, beta2, eps, weight_decay, dyn):
+    """Adam with the step-dependent scalars in the device buffer `dyn` (2 floats): for launches captured into a hipGraph."""
+    lib = _lib.load()
+    _same_device(p, g, m, v, dyn)
+    with _on(p):
+        _lib.check(lib.munit_adam_step_graph(_p(p), _p(g), _p(m), _p(v), p.numel(), float(beta1), float(beta2),
+                                             float(eps), float(weight_decay), _p(dyn), _stream()), "adam_step_graph")
+
+
+def adam_dynamic_scalars(lr, beta1, beta2, step):
+    out = (c_float * 2)()
+    _lib.load().munit_adam_dynamic_scalars(float(lr), float(beta1), float(beta2), int(step), out)
+    return out[0], out[1]
+
+
 def extraadam_step(p, g, m, v, p_saved, lr, beta1, beta2, eps, weight_decay, step, mode):
     lib = _lib.load()
     for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq"), (p_saved, "saved params")):

@@ -44,6 +44,9 @@ class FusedAdam(Optimizer):
         # prepared weight images (ops._prepared): items registered on first use, refreshed in one launch per step
         self._prep_items = []
         self._prep_table = None
+        # hipGraph mode (munit_amd/graph.py): the step-dependent scalars of the update live in a device buffer that the
+        # replaying host refreshes; step() then neither counts steps nor bakes lr into its launch
+        self.dyn = None
 
     # ---- flat storage -----------------------------------------------------------------
     @staticmethod
@@ -116,10 +119,23 @@ class FusedAdam(Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self._step += 1
-        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
-                      g["eps"], g["weight_decay"], self._step)
+        if self.dyn is not None:
+            ops.adam_step_graph(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["betas"][0], g["betas"][1],
+                                g["eps"], g["weight_decay"], self.dyn)
+        else:
+            self._step += 1
+            ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
+                          g["eps"], g["weight_decay"], self._step)
         self.refresh_prepared()
+
+    def advance_dynamic(self, pinned):
+        """hipGraph mode: count the step on the host and hand the device its scalars (lr / (1 - beta1^t), sqrt(1 -
+        beta2^t)) through the pinned staging buffer; the copy is ordered on the current stream before the replay."""
+        g = self.param_groups[0]
+        self._step += 1
+        a, b = ops.adam_dynamic_scalars(g["lr"], g["betas"][0], g["betas"][1], self._step)
+        pinned[0], pinned[1] = a, b
+        self.dyn.copy_(pinned, non_blocking=True)
 
     def state_dict(self):
         state = {}

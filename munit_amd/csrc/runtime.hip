@@ -32,8 +32,21 @@ extern "C" int munit_stream_wait_stream(munit_stream_t waiter, munit_stream_t si
     munit_set_error("stream_wait_stream: hipEventCreate failed");
     return MUNIT_ERR_LAUNCH;
   }
-  hipError_t e = hipEventRecord(ev[dev], (hipStream_t)signaler);
-  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev[dev], 0);
+  // Inside a stream capture every fork / join edge gets an event of its own (re-recording one event object while the
+  // graph under construction still refers to its previous record crashed hipStreamEndCapture on ROCm 7.2); these few
+  // hundred events per captured step are kept until the process ends.
+  hipEvent_t use = ev[dev];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)signaler, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+    if (hipEventCreateWithFlags(&use, hipEventDisableTiming) != hipSuccess) {
+      munit_set_error("stream_wait_stream: hipEventCreate failed (capture)");
+      return MUNIT_ERR_LAUNCH;
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  hipError_t e = hipEventRecord(use, (hipStream_t)signaler);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, use, 0);
   if (e != hipSuccess) {
     munit_set_error("stream_wait_stream: %s", hipGetErrorString(e));
     return MUNIT_ERR_LAUNCH;

@@ -1,0 +1,27 @@
+"""Bisect tool for hipGraph capture of the step: python tools/graph_probe.py <what>  (what: fwd | dis | gen | both)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from munit_amd.trainer import MUNIT_Trainer
+what = sys.argv[1]
+dev = torch.device("cuda:0")
+hp = bench.bench_hp(64, 2)
+torch.manual_seed(1234)
+tr = MUNIT_Trainer(hp); tr.to(dev)
+x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(2, 64))
+def run():
+    if what == "fwd":
+        with torch.no_grad():
+            c, s = tr.gen.encode(x_a, 1); return tr.gen.decode(c, s, 2)
+    if what in ("dis", "both"): tr.dis_update(x_a, x_b, hp)
+    if what in ("gen", "both"): tr.gen_update(x_a, x_b, hp, m_a, m_b)
+for _ in range(2): run()
+torch.cuda.synchronize()
+for opt in (tr.dis_opt, tr.gen_opt):
+    opt.dyn = torch.tensor([2e-4, 0.0316], device=dev)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    run()
+print("captured", what, flush=True)
+g.replay(); torch.cuda.synchronize()
+print("replayed", what, float(tr.loss_dis_total) if what != "fwd" and what != "gen" else "", flush=True)

@@ -362,10 +362,18 @@ def _side_stream(device):
     return st
 
 
+def stream_wait(waiter, signaler):
+    """`waiter` (torch.cuda.Stream) waits for everything enqueued so far on `signaler`, through the library's cached /
+    capture-safe events (munit_stream_wait_stream) instead of a torch Event object per edge."""
+    with torch.cuda.device(waiter.device):
+        _lib.check(_lib.load().munit_stream_wait_stream(c_void_p(waiter.cuda_stream), c_void_p(signaler.cuda_stream)),
+                   "stream_wait_stream")
+
+
 def join_side_streams():
     """Make the current stream wait for every backward-weight launched so far (call before the optimizer step)."""
     for (_, index), st in _SIDE.items():
-        torch.cuda.current_stream(torch.device("cuda", index)).wait_stream(st)
+        stream_wait(torch.cuda.current_stream(torch.device("cuda", index)), st)
 
 
 class _Conv2d(Function):

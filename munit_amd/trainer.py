@@ -224,7 +224,7 @@ class _Branches:
             _Branches._streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self.s = _Branches._streams[key]
         for st in self.s:
-            st.wait_stream(self.main)
+            ops.stream_wait(st, self.main)
 
     def run(self, k, fn):
         if not self.enabled:
@@ -235,9 +235,10 @@ class _Branches:
     def share(self, *tensors):
         if not self.enabled:
             return
-        ea, eb = self.s[0].record_event(), self.s[1].record_event()
-        self.s[0].wait_event(eb)
-        self.s[1].wait_event(ea)
+        # each branch waits for the other's work so far (events of the library: they stay valid inside a graph capture,
+        # where ROCm 7.2 crashed on torch's short-lived Event objects)
+        ops.stream_wait(self.s[0], self.s[1])
+        ops.stream_wait(self.s[1], self.s[0])
         for t in tensors:
             if torch.is_tensor(t):
                 t.record_stream(self.s[0])
@@ -247,7 +248,7 @@ class _Branches:
         if not self.enabled:
             return
         for st in self.s:
-            self.main.wait_stream(st)
+            ops.stream_wait(self.main, st)
         for t in tensors:
             if torch.is_tensor(t):
                 t.record_stream(self.main)

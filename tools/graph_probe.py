@@ -9,7 +9,21 @@ hp = bench.bench_hp(64, 2)
 torch.manual_seed(1234)
 tr = MUNIT_Trainer(hp); tr.to(dev)
 x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(2, 64))
+if os.environ.get("MUNIT_PROBE_NO_RECORD_STREAM"):
+    torch.Tensor.record_stream = lambda self, s: None
+from munit_amd.trainer import _Branches
 def run():
+    if what == "brfwd":      # the two encodes on the branch streams, no autograd
+        with torch.no_grad():
+            br = _Branches(dev)
+            br.share(x_a, x_b)
+            c_a, s_a = br.run(0, lambda: tr.gen.encode(x_a, 1))
+            c_b, s_b = br.run(1, lambda: tr.gen.encode(x_b, 2))
+            br.share(c_a, c_b, s_a, s_b)
+            y = br.run(0, lambda: tr.gen.decode(c_b, s_a, 1))
+            z = br.run(1, lambda: tr.gen.decode(c_a, s_b, 2))
+            br.join(y, z)
+            return y, z
     if what == "fwd":
         with torch.no_grad():
             c, s = tr.gen.encode(x_a, 1); return tr.gen.decode(c, s, 2)

@@ -13,6 +13,26 @@ if os.environ.get("MUNIT_PROBE_NO_RECORD_STREAM"):
     torch.Tensor.record_stream = lambda self, s: None
 from munit_amd.trainer import _Branches
 def run():
+    if what.startswith("v"):
+        with torch.no_grad():
+            br = _Branches(dev)
+            y = z = None
+            if what == "v0":                      # a torch stream context without the fork helper
+                st = torch.cuda.Stream(device=dev) if not hasattr(run, "st") else run.st
+                run.st = st
+                from munit_amd import ops
+                ops.stream_wait(st, torch.cuda.current_stream(dev))
+                with torch.cuda.stream(st):
+                    y = tr.gen.encode(x_a, 1)[0]
+                ops.stream_wait(torch.cuda.current_stream(dev), st)
+                return y
+            if what in ("v2", "v3", "v4"):
+                if what == "v4": br.share(x_a, x_b)
+                y = br.run(0, lambda: tr.gen.encode(x_a, 1))
+            if what in ("v3", "v4"):
+                z = br.run(1, lambda: tr.gen.encode(x_b, 2))
+            br.join(y, z)
+            return y, z
     if what == "brfwd":      # the two encodes on the branch streams, no autograd
         with torch.no_grad():
             br = _Branches(dev)

@@ -58,6 +58,8 @@ const char* munit_last_error(void);
  * for all work enqueued so far on `signaler`; both streams belong to the current device.  Used to fork backward-weight
  * onto a side stream without creating torch Event / Stream objects per layer. */
 int munit_stream_wait_stream(munit_stream_t waiter, munit_stream_t signaler);
+/* a and b each wait for what the other has enqueued so far (the cross-over points of the trainer's two branch streams). */
+int munit_stream_cross_wait(munit_stream_t a, munit_stream_t b);
 
 /* ------------------------------------------------------------------------------------
  * Convolution.  Replaces nn.ReflectionPad2d/ZeroPad2d + nn.Conv2d (+ bias + activation)

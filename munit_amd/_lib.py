@@ -47,6 +47,7 @@ SIGNATURES = {
     "munit_version": (c_int, []),
     "munit_last_error": (c_char_p, []),
     "munit_stream_wait_stream": (c_int, [_P, _P]),
+    "munit_stream_cross_wait": (c_int, [_P, _P]),
     "munit_conv2d_out_hw": (c_int, [_DESC, POINTER(c_int), POINTER(c_int)]),
     "munit_conv2d_fwd_workspace_bytes": (c_size_t, [_DESC]),
     "munit_conv2d_fwd": (c_int, [_DESC, _P, _P, _P, _P, _P, c_size_t, _P]),

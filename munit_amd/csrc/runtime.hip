@@ -53,3 +53,30 @@ extern "C" int munit_stream_wait_stream(munit_stream_t waiter, munit_stream_t si
   }
   return MUNIT_OK;
 }
+
+// a and b each wait for what the other has enqueued so far: both events are recorded first, then both waits are issued
+// (a record that follows a wait on the other stream builds a chained edge inside a capture, which hipStreamEndCapture of
+// ROCm 7.2 did not survive when neither stream had a kernel node yet).
+extern "C" int munit_stream_cross_wait(munit_stream_t a, munit_stream_t b) {
+  hipEvent_t ea, eb;
+  if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
+    munit_set_error("stream_cross_wait: hipEventCreate failed");
+    return MUNIT_ERR_LAUNCH;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing((hipStream_t)a, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+  if (!capturing) (void)hipGetLastError();
+  hipError_t e = hipEventRecord(ea, (hipStream_t)a);
+  if (e == hipSuccess) e = hipEventRecord(eb, (hipStream_t)b);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)a, eb, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)b, ea, 0);
+  if (!capturing) {   // outside a capture the events can go at once (destruction is deferred until they complete)
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+  }
+  if (e != hipSuccess) {
+    munit_set_error("stream_cross_wait: %s", hipGetErrorString(e));
+    return MUNIT_ERR_LAUNCH;
+  }
+  return MUNIT_OK;
+}

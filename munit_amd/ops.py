@@ -370,6 +370,12 @@ def stream_wait(waiter, signaler):
                    "stream_wait_stream")
 
 
+def stream_cross_wait(a, b):
+    """Streams a and b each wait for the other's work so far."""
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().munit_stream_cross_wait(c_void_p(a.cuda_stream), c_void_p(b.cuda_stream)), "stream_cross_wait")
+
+
 def join_side_streams():
     """Make the current stream wait for every backward-weight launched so far (call before the optimizer step)."""
     for (_, index), st in _SIDE.items():

@@ -237,8 +237,7 @@ class _Branches:
             return
         # each branch waits for the other's work so far (events of the library: they stay valid inside a graph capture,
         # where ROCm 7.2 crashed on torch's short-lived Event objects)
-        ops.stream_wait(self.s[0], self.s[1])
-        ops.stream_wait(self.s[1], self.s[0])
+        ops.stream_cross_wait(self.s[0], self.s[1])
         for t in tensors:
             if torch.is_tensor(t):
                 t.record_stream(self.s[0])

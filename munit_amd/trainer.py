@@ -232,6 +232,18 @@ class _Branches:
         with torch.cuda.stream(self.s[k]):
             return fn()
 
+    def adopt(self, *tensors):
+        """Tensors that already exist on the caller's stream become usable on both branches: the fork in __init__ ordered
+        the branches behind the caller's stream, so only the allocator has to be told (no cross-over wait: besides being
+        redundant, a cross-over between two branches that hold no kernel yet is what hipStreamEndCapture of ROCm 7.2
+        crashes on when the step is captured into a graph)."""
+        if not self.enabled:
+            return
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self.s[0])
+                t.record_stream(self.s[1])
+
     def share(self, *tensors):
         if not self.enabled:
             return
@@ -445,7 +457,7 @@ class MUNIT_Trainer(nn.Module):
             p.requires_grad_(False)
         try:
             br = _Branches(dev)
-            br.share(x_a, x_b, mask_a, mask_b)
+            br.adopt(x_a, x_b, mask_a, mask_b)
             c_a, s_a_prime = br.run(0, lambda: self._enc(x_a, 1))
             c_b, s_b_prime = br.run(1, lambda: self._enc(x_b, 2))
             x_a_recon = br.run(0, lambda: self._dec(c_a, s_a_prime, 1))
@@ -525,7 +537,7 @@ class MUNIT_Trainer(nn.Module):
         dev = x_a.device
         x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
         br = _Branches(dev)
-        br.share(x_a, x_b)
+        br.adopt(x_a, x_b)
         with torch.no_grad():  # the generator graph would never be back-propagated here
             c_a, s_a_prime = br.run(0, lambda: self._enc(x_a, 1))
             c_b, s_b_prime = br.run(1, lambda: self._enc(x_b, 2))

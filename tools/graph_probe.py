@@ -36,7 +36,7 @@ def run():
     if what == "brfwd":      # the two encodes on the branch streams, no autograd
         with torch.no_grad():
             br = _Branches(dev)
-            br.share(x_a, x_b)
+            br.adopt(x_a, x_b)
             c_a, s_a = br.run(0, lambda: tr.gen.encode(x_a, 1))
             c_b, s_b = br.run(1, lambda: tr.gen.encode(x_b, 2))
             br.share(c_a, c_b, s_a, s_b)

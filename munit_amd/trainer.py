@@ -247,9 +247,13 @@ class _Branches:
     def share(self, *tensors):
         if not self.enabled:
             return
-        # each branch waits for the other's work so far (events of the library: they stay valid inside a graph capture,
-        # where ROCm 7.2 crashed on torch's short-lived Event objects)
-        ops.stream_cross_wait(self.s[0], self.s[1])
+        # cross-over = join into the caller's stream + fork again: the same ordering as a pairwise wait between the two
+        # branches, but built from the fork / join edges that a graph capture accepts (hipStreamEndCapture of ROCm 7.2
+        # crashes on a direct cross dependency between two forked streams); the caller's stream is idle meanwhile
+        for st in self.s:
+            ops.stream_wait(self.main, st)
+        for st in self.s:
+            ops.stream_wait(st, self.main)
         for t in tensors:
             if torch.is_tensor(t):
                 t.record_stream(self.s[0])

@@ -5,7 +5,8 @@ of host time per step, per rank.  `GraphedStep` runs the step eagerly a few time
 weight images, workspaces, occupancy queries -- is warm afterwards), captures one more pass into a hipGraph through
 `torch.cuda.graph` (the branch streams and the backward-weight side stream fork from and re-join the capture stream, so
 the whole multi-stream schedule is part of the graph) and from then on replays it: the host cost of a step becomes a few
-small copies and one graph launch.
+small copies and one graph launch.  Device time is HIGHER than the eager three-stream schedule's (see below: the
+generator update loses its a / b overlap inside a capture), so this is for host-bound situations, not the default.
 
 What changes between replays lives in device memory: the batch (static input buffers, copied into before the replay),
 and the two step-dependent scalars of each Adam update (`FusedAdam.dyn`, refreshed from the host: the learning-rate
@@ -37,9 +38,20 @@ class GraphedStep:
                        else t.detach().clone() for t in (x_a, x_b, mask_a, mask_b)]
         self._opts = (trainer.dis_opt, trainer.gen_opt)
 
+        from . import trainer as trainer_mod
+
         def updates():
             trainer.dis_update(self.static[0], self.static[1], hp)
-            trainer.gen_update(self.static[0], self.static[1], hp, self.static[2], self.static[3])
+            # gen_update is captured WITHOUT the a / b branch streams (the backward-weight side stream stays): its
+            # backward carries gradients across the two branches (c_a, c_b, the style codes), and the cross-stream
+            # dependencies the autograd engine then records crash hipStreamEndCapture on ROCm 7.2 (bisected with
+            # tools/graph_probe.py: dis_update, whose two discriminators never exchange gradients, captures fine).
+            saved = trainer_mod.BRANCH_STREAMS
+            trainer_mod.BRANCH_STREAMS = False
+            try:
+                trainer.gen_update(self.static[0], self.static[1], hp, self.static[2], self.static[3])
+            finally:
+                trainer_mod.BRANCH_STREAMS = saved
 
         for _ in range(warmup):                      # eager: fills every cache the capture must not touch
             trainer.update_learning_rate()

@@ -250,9 +250,11 @@ int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, doub
 
 /* The same update for a launch that is captured into a hipGraph and replayed (munit_amd/graph.py): the two scalars that
  * change from step to step -- lr / (1 - beta1^t) and sqrt(1 - beta2^t) -- are read from dyn[0], dyn[1] in DEVICE memory,
- * which the host refreshes before every replay with the values munit_adam_dynamic_scalars computes (the same double ->
- * float conversions as munit_adam_step, so the replayed step is bit-identical to the eager one). */
+ * which the host refreshes before every replay (munit_store_floats: the values travel as kernel arguments, so a host
+ * running ahead of the device cannot overwrite a pending update) with the values munit_adam_dynamic_scalars computes
+ * (the same double -> float conversions as munit_adam_step, so the replayed step is bit-identical to the eager one). */
 void munit_adam_dynamic_scalars(double lr, double beta1, double beta2, int step, float* out2 /* host, 2 floats */);
+int munit_store_floats(float* dst, const float* vals_host, int n /* <= 8 */, munit_stream_t stream);
 int munit_adam_step_graph(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2,
                           double eps, double weight_decay, const float* dyn, munit_stream_t stream);
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     "munit_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int,
                                 _P]),
     "munit_adam_dynamic_scalars": (None, [c_double, c_double, c_double, c_int, POINTER(c_float)]),
+    "munit_store_floats": (c_int, [_P, POINTER(c_float), c_int, _P]),
     "munit_adam_step_graph": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, _P, _P]),
     "munit_extraadam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double,
                                      c_double, c_int, c_int, _P]),

@@ -413,6 +413,25 @@ extern "C" void munit_adam_dynamic_scalars(double lr, double beta1, double beta2
   out2[1] = (float)sqrt(bc2);
 }
 
+namespace {
+struct Small8 { float v[8]; };
+__global__ void store_floats_kernel(float* dst, Small8 vals, int n) {
+  if (threadIdx.x < (unsigned)n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+}  // namespace
+
+// dst[i] = vals[i] (i < n <= 8; vals on the HOST).  The values travel as kernel arguments, i.e. they are read when the
+// call is made, not when the stream gets to it: a host that runs ahead of the device cannot overwrite them (a pinned
+// staging buffer reused every step raced with its own pending copy).
+extern "C" int munit_store_floats(float* dst, const float* vals, int n, munit_stream_t stream) {
+  MUNIT_CHECK_ARG(dst && vals && n > 0 && n <= 8, "store_floats: bad args");
+  Small8 s{};
+  for (int i = 0; i < n; ++i) s.v[i] = vals[i];
+  hipLaunchKernelGGL(store_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, s, n);
+  MUNIT_CHECK_LAUNCH("store_floats");
+  return MUNIT_OK;
+}
+
 extern "C" int munit_adam_step_graph(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2,
                                      double eps, double weight_decay, const float* dyn, munit_stream_t stream) {
   MUNIT_CHECK_ARG(p && g && m && v && dyn && n > 0, "adam_step_graph: bad args");

@@ -57,10 +57,8 @@ class GraphedStep:
             trainer.update_learning_rate()
             updates()
         torch.cuda.synchronize(x_a.device)
-        self._pinned = []
         for opt in self._opts:
             opt.dyn = torch.zeros(2, dtype=torch.float32, device=x_a.device)
-            self._pinned.append(torch.zeros(2, dtype=torch.float32).pin_memory())
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):       # nothing executes here: the launches are recorded
@@ -76,8 +74,8 @@ class GraphedStep:
         for dst, src in zip(self.static, (x_a, x_b, mask_a, mask_b)):
             if dst is not None:
                 dst.copy_(src, non_blocking=True)
-        for opt, pin in zip(self._opts, self._pinned):
-            opt.advance_dynamic(pin)
+        for opt in self._opts:
+            opt.advance_dynamic()
         self.graph.replay()
 
     def release(self):

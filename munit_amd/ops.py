@@ -762,10 +762,14 @@ def adam_step_graph(p, g, m, v, beta1, beta2, eps, weight_decay, dyn):
                                              float(eps), float(weight_decay), _p(dyn), _stream()), "adam_step_graph")
 
 
-def adam_dynamic_scalars(lr, beta1, beta2, step):
+def adam_dynamic_scalars(lr, beta1, beta2, step, dyn):
+    """Compute the step's (lr / (1 - beta1^t), sqrt(1 - beta2^t)) and store them into the device buffer `dyn`, ordered on
+    the current stream; the values are captured when this call is made."""
+    lib = _lib.load()
     out = (c_float * 2)()
-    _lib.load().munit_adam_dynamic_scalars(float(lr), float(beta1), float(beta2), int(step), out)
-    return out[0], out[1]
+    lib.munit_adam_dynamic_scalars(float(lr), float(beta1), float(beta2), int(step), out)
+    with _on(dyn):
+        _lib.check(lib.munit_store_floats(_p(dyn), out, 2, _stream()), "store_floats")
 
 
 def extraadam_step(p, g, m, v, p_saved, lr, beta1, beta2, eps, weight_decay, step, mode):

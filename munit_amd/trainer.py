@@ -128,14 +128,12 @@ class FusedAdam(Optimizer):
                           g["eps"], g["weight_decay"], self._step)
         self.refresh_prepared()
 
-    def advance_dynamic(self, pinned):
+    def advance_dynamic(self):
         """hipGraph mode: count the step on the host and hand the device its scalars (lr / (1 - beta1^t), sqrt(1 -
-        beta2^t)) through the pinned staging buffer; the copy is ordered on the current stream before the replay."""
+        beta2^t)), ordered on the current stream before the replay."""
         g = self.param_groups[0]
         self._step += 1
-        a, b = ops.adam_dynamic_scalars(g["lr"], g["betas"][0], g["betas"][1], self._step)
-        pinned[0], pinned[1] = a, b
-        self.dyn.copy_(pinned, non_blocking=True)
+        ops.adam_dynamic_scalars(g["lr"], g["betas"][0], g["betas"][1], self._step, self.dyn)
 
     def state_dict(self):
         state = {}

@@ -129,7 +129,8 @@ class _Plan(object):
     """Everything about one layer geometry that does not change between calls: the descriptor, output extent,
     workspace sizes and prepared-weight sizes of the three passes.  Built once per (shape, config) -- the C-ABI
     queries behind it cost more host time than the launch itself when they are repeated ~500 times per step."""
-    __slots__ = ("d", "ref", "ho", "wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "prep_bytes", "tag", "flop", "flop_exec")
+    __slots__ = ("d", "ref", "ho", "wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "prep_bytes", "prep_sig", "tag", "flop",
+                 "flop_exec")
 
 
 _plans = {}
@@ -152,6 +153,14 @@ def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none
     pl.ws_dgrad = lib.munit_conv2d_dgrad_workspace_bytes(pl.ref)
     pl.ws_wgrad = lib.munit_conv2d_wgrad_workspace_bytes(pl.ref)
     pl.prep_bytes = (lib.munit_conv2d_prepared_weight_bytes(pl.ref, 0), lib.munit_conv2d_prepared_weight_bytes(pl.ref, 1))
+    # what kind of image each pass wants (kind, stride phases, bf16): one weight may meet several (an fp32 and a bf16
+    # use of the same layer), and each gets an image of its own
+    sig = []
+    for which in (0, 1):
+        item = _lib.PrepItem()
+        rc = lib.munit_conv2d_prep_item(pl.ref, which, None, None, byref(item))
+        sig.append((which, item.kind, item.ps, item.bf16) if rc == 0 else (which, 0, 0, 0))
+    pl.prep_sig = tuple(sig)
     pl.tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if cout <= 64 else 128, "true" if cin % 32 == 0 else "false")
     if pl.ws_fwd:
         pl.tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
@@ -221,7 +230,8 @@ def _prepared(owner, w, pl, which):
     reg = getattr(owner, "_munit_prep", None)
     if reg is None or w.data_ptr() != owner.data_ptr():
         return None
-    ent = reg.get(which)
+    key = pl.prep_sig[which]
+    ent = reg.get(key)
     ver = owner._version
     if ent is not None and ent[1] == ver:
         return ent[0]
@@ -232,7 +242,7 @@ def _prepared(owner, w, pl, which):
         item = _lib.PrepItem()
         _lib.check(lib.munit_conv2d_prep_item(pl.ref, which, _p(w), _p(buf), byref(item)), "conv2d_prep_item")
         ent = [buf, ver, item]
-        reg[which] = ent
+        reg[key] = ent
     _lib.check(lib.munit_conv2d_prepare_weights(byref(ent[2]), _stream()), "conv2d_prepare_weights")
     ent[1] = ver
     # other streams may use the image right away (the a / b branches share the style encoder): rare path, so simply

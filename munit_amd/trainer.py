@@ -298,6 +298,7 @@ class MUNIT_Trainer(nn.Module):
         # benchmark's step is defined on the reference's sequence of computations.
         self.reuse_dis_forward = bool(hyperparameters.get("reuse_dis_forward", 0))
         self._fwd_cache = None
+        self.fwd_reused = False     # whether the last gen_update continued from dis_update's forward
 
         optimizer = FusedExtraAdam if "extra" in hyperparameters["optimizer"] else FusedAdam  # trainer.py:41-45
         self.domain_classif_ab = hyperparameters.get("domain_adv_w", 0) > 0
@@ -461,6 +462,7 @@ class MUNIT_Trainer(nn.Module):
         s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
         s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
         dev = x_a.device
+        fwd_key = self._fwd_key(x_a, x_b)      # of the caller's tensors (the layout conversion below may copy)
         x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
 
         d_params = list(self.dis_a.parameters()) + list(self.dis_b.parameters())
@@ -470,7 +472,8 @@ class MUNIT_Trainer(nn.Module):
             br = _Branches(dev)
             br.adopt(x_a, x_b, mask_a, mask_b)
             cached, self._fwd_cache = self._fwd_cache, None
-            reuse = (cached is not None and self.guided == 1 and cached[0] == self._fwd_key(x_a, x_b))
+            reuse = (cached is not None and self.guided == 1 and cached[0] == fwd_key)
+            self.fwd_reused = reuse
             if reuse:      # the forward dis_update just ran on these tensors with these generator weights
                 c_a, s_a_prime, c_b, s_b_prime, x_ba_kept, x_ab_kept = cached[1]
                 br.adopt(c_a, s_a_prime, c_b, s_b_prime, x_ba_kept, x_ab_kept)
@@ -556,6 +559,7 @@ class MUNIT_Trainer(nn.Module):
         s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
         s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
         dev = x_a.device
+        fwd_key = self._fwd_key(x_a, x_b)
         x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
         br = _Branches(dev)
         br.adopt(x_a, x_b)
@@ -574,7 +578,7 @@ class MUNIT_Trainer(nn.Module):
             x_ba = br.run(0, lambda: self._dec(c_b, s_a_use, 1))
             x_ab = br.run(1, lambda: self._dec(c_a, s_b_use, 2))
         if keep:
-            self._fwd_cache = (self._fwd_key(x_a, x_b), (c_a, s_a_prime, c_b, s_b_prime, x_ba, x_ab))
+            self._fwd_cache = (fwd_key, (c_a, s_a_prime, c_b, s_b_prime, x_ba, x_ab))
         self.loss_dis_a = br.run(0, lambda: self.dis_a.calc_dis_loss(x_ba.detach(), x_a))
         self.loss_dis_b = br.run(1, lambda: self.dis_b.calc_dis_loss(x_ab.detach(), x_b))
         br.join(self.loss_dis_a, self.loss_dis_b)

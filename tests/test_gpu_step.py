@@ -355,11 +355,12 @@ def test_reuse_dis_forward_is_bitwise_the_plain_step():
             tr.dis_update(b[0], b[1], hp)
             assert (tr._fwd_cache is not None) == bool(reuse)
             tr.gen_update(b[0], b[1], hp, b[2], b[3])
-            assert tr._fwd_cache is None
+            assert tr._fwd_cache is None and tr.fwd_reused == bool(reuse)
         # a mismatch: dis_update on one batch, gen_update on another -> the kept forward is dropped, not used
         tr.update_learning_rate()
         tr.dis_update(b0[0], b0[1], hp)
         tr.gen_update(b1[0], b1[1], hp, b1[2], b1[3])
+        assert not tr.fwd_reused
         torch.cuda.synchronize()
         return tr.gen_opt.flat_p.clone(), tr.dis_opt.flat_p.clone(), float(tr.loss_gen_total.detach()), float(tr.loss_dis_total.detach())
 

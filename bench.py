@@ -411,8 +411,8 @@ def main():
         ops.set_compute("f32")
         torch.cuda.empty_cache()
         # supplementary, NOT the metric: fp32 with `reuse_dis_forward: 1` -- gen_update continues from the generator forward
-        # that dis_update ran on the same batch instead of recomputing it as the reference does (bit-identical results,
-        # 11 % fewer multiply-accumulates)
+        # that dis_update ran on the same batch instead of recomputing it as the reference does (same losses bit for
+        # bit, gradients to fp32 summation order, 11 % fewer multiply-accumulates)
         hp3 = dict(hp)
         hp3["reuse_dis_forward"] = 1
         torch.manual_seed(1234)

@@ -294,8 +294,10 @@ class MUNIT_Trainer(nn.Module):
         # decode x_ab -- on the same images with the same generator weights (only the discriminators step in between);
         # the reference computes it twice (trainer.py:1146-1179 under no autograd, then trainer.py:366-390).  With this
         # switch dis_update keeps that forward and its autograd tape and gen_update continues from it when it is handed
-        # the very same tensors: 11 % fewer multiply-accumulates per step, bit-identical results.  Off by default: the
-        # benchmark's step is defined on the reference's sequence of computations.
+        # the very same tensors: 11 % fewer multiply-accumulates per step; the forward values (and therefore every
+        # loss) are the same numbers, the gradients agree to fp32 summation order (the kept nodes are older on the autograd
+        # tape, so the uses of a shared weight accumulate in another order).  Off by default: the benchmark's step is
+        # defined on the reference's sequence of computations.
         self.reuse_dis_forward = bool(hyperparameters.get("reuse_dis_forward", 0))
         self._fwd_cache = None
         self.fwd_reused = False     # whether the last gen_update continued from dis_update's forward

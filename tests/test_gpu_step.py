@@ -377,3 +377,36 @@ def test_reuse_dis_forward_matches_the_plain_step():
     assert l2err(got[0][0], ref[0][0]) <= 1e-5, l2err(got[0][0], ref[0][0])
     for a, b in zip(ref[1:], got[1:]):                             # after four Adam steps on re-ordered sums
         assert abs(a - b) <= 2e-3 * abs(a), (a, b)
+
+
+def test_training_reduces_the_reconstruction_losses():
+    """End-to-end sanity of the optimisation loop (not a parity check): 80 iterations of update_learning_rate + dis_update +
+    gen_update on one fixed two-domain batch must drive the within-domain and the cycle reconstruction losses down, keep
+    every loss finite, and leave the adversarial game bounded."""
+    import bench
+    from munit_amd.trainer import MUNIT_Trainer
+    dev = torch.device("cuda:0")
+    size, batch = 64, 2
+    hp = bench.bench_hp(size, batch)
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(hp)
+    tr.to(dev)
+    g = torch.Generator().manual_seed(3)
+    # smooth images (a random low-resolution field up-sampled) are learnable; uniform noise would not be
+    low = torch.rand(2 * batch, 3, 8, 8, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False) * 2 - 1
+    x_a, x_b = img[:batch].to(dev), img[batch:].to(dev)
+    m = torch.zeros(batch, 1, size, size, device=dev)
+    hist = []
+    for it in range(80):
+        tr.iterations = it
+        tr.update_learning_rate()
+        tr.dis_update(x_a, x_b, hp)
+        tr.gen_update(x_a, x_b, hp, m, m)
+        if it % 10 == 0 or it == 79:
+            hist.append((float(tr.loss_gen_recon_x_a.detach()), float(tr.loss_gen_cycrecon_x_a.detach()),
+                         float(tr.loss_gen_total.detach()), float(tr.loss_dis_total.detach())))
+    print(hist)
+    assert all(v == v and abs(v) < 1e4 for h in hist for v in h)
+    assert hist[-1][0] < 0.6 * hist[0][0], (hist[0], hist[-1])      # within-domain reconstruction
+    assert hist[-1][1] < 0.8 * hist[0][1], (hist[0], hist[-1])      # cycle reconstruction

@@ -551,6 +551,10 @@ class OracleTrainer:
             sa_use, sb_use = s_a, s_b
         x_ba = ga.decode(c_b, sa_use, ka)
         x_ab = gb.decode(c_a, sb_use, kb)
+        # the adversarial terms (trainer.py:515-516) are evaluated here, as soon as the translations exist: the value is
+        # the same wherever they stand, and the HIP trainer issues them at this point (tests replay its activation order)
+        adv_a = dis_loss_g(self.dis_a, "", x_ba, hp["dis"])
+        adv_b = dis_loss_g(self.dis_b, "", x_ab, hp["dis"])
         c_b_recon, s_a_recon = ga.encode(x_ba, ka)
         c_a_recon, s_b_recon = gb.encode(x_ab, kb)
         L: Dict[str, Tensor] = {}
@@ -573,8 +577,8 @@ class OracleTrainer:
         else:
             L["loss_gen_cycrecon_x_a"] = zero
             L["loss_gen_cycrecon_x_b"] = zero
-        L["loss_gen_adv_a"] = dis_loss_g(self.dis_a, "", x_ba, hp["dis"])
-        L["loss_gen_adv_b"] = dis_loss_g(self.dis_b, "", x_ab, hp["dis"])
+        L["loss_gen_adv_a"] = adv_a
+        L["loss_gen_adv_b"] = adv_b
         L["loss_gen_total"] = (
             hp["gan_w"] * L["loss_gen_adv_a"] + hp["gan_w"] * L["loss_gen_adv_b"]
             + hp["recon_x_w"] * L["loss_gen_recon_x_a"] + hp["recon_s_w"] * L["loss_gen_recon_s_a"]

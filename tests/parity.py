@@ -37,14 +37,15 @@ class GradCheck:
     the kernels, and it used to be absorbed by a 5e-2 / 1e-1 per-tensor bound.  Now the HIP forward records the sign
     pattern behind every ReLU / LeakyReLU (ops.MASK_SINK) and the fp64 oracle takes the same branches
     (oracle.KINK_MASKS), so both sides differentiate the same piecewise-linear function and the comparison is tight:
-        pinned:    every tensor <= 1e-2 normalised max AND <= 1e-2 relative L2, median L2 <= 1e-3
+        pinned:    every tensor <= 5e-3 normalised max AND <= 2e-3 relative L2, median L2 <= 3e-4  (measured on MI355X,
+                   3 iterations at 64x64: worst 1.5e-3 max / 3.7e-4 L2 -- half of SURVEY's 1e-2 is the hard bound)
         unpinned:  (diagnostic mode, pin_kinks=False) every tensor <= 5e-2 L2 / 1e-1 max, median <= 2e-3, and at
                    most 10 % of the tensors looser than 1e-2 max -- listed by name in the report."""
 
     def __init__(self, pinned=True):
         self.pinned = pinned
         if pinned:
-            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 1e-3, 1e-2, 1e-2
+            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 3e-4, 2e-3, 5e-3
         else:
             self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 2e-3, 5e-2, 1e-1
         self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0

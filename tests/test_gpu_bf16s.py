@@ -160,7 +160,7 @@ def test_l1_bf16_storage():
     a, b = r16(rnd((2, 64, 9, 7), 13)), r16(rnd((2, 64, 9, 7), 14))
     ad, bd = to_dev(a, BF).requires_grad_(True), to_dev(b, BF).requires_grad_(True)
     out = ops.l1_mean(ad, bd)
-    assert out.dtype == F32 and abs(float(out) - float((a - b).abs().mean())) <= 1e-5
+    assert out.dtype == F32 and abs(float(out.detach()) - float((a - b).abs().mean())) <= 1e-5
     out.backward()
     g = torch.sign(a - b) / a.numel()
     assert ad.grad.dtype == BF and nerr(ad.grad, g) <= BF16_OUT and nerr(bd.grad, -g) <= BF16_OUT

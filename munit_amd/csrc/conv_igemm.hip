@@ -13,6 +13,7 @@
 // stage through registers into [row][36] (pad 4 => conflict-free ds_read_b128: one b128 feeds 4 MFMA k-steps).
 // Tiles are double-buffered with one barrier per K-tile.  DESIGN.md section 3.1.
 #include "common.h"
+#include "wino.h"
 #include <cstdlib>
 
 namespace {
@@ -873,6 +874,7 @@ __device__ inline void prep_subpixel_elem(const PrepItem& it, long long i) {
 __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
+  if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
   return cc * it.KH * it.KW;
 }
 
@@ -884,6 +886,8 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
   const long long total = prep_elems(it);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
+    else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
+      it.wp[i] = wino_weight_elem(it.w, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
@@ -1178,6 +1182,13 @@ bool cin4_fwd_ok(const munit_conv_desc* d) {
          NWAVES == 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_CIN4");
 }
 
+// 3x3 / stride 1 / pad 1 fp32 layers with wide channel counts: Winograd F(2x2, 3x3) (conv_wino.hip)
+bool wino_geometry_ok(const munit_conv_desc* d) {
+  return d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 &&
+         d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH;
+}
+bool wino_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
+
 // forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
 munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* wp) {
   munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1, 0};
@@ -1185,6 +1196,7 @@ munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* w
   if (small) return it;
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
   if (subpixel_ok(d)) it.kind = MUNIT_PREP_SUBPIXEL;
+  else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
   else if (it.bf16) it.kind = MUNIT_PREP_CAST;
   return it;
 }
@@ -1198,7 +1210,7 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
-  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16) return img;
+  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d)) return img;
   if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
     const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
     return c.x4_bytes + c.w4_bytes;
@@ -1242,6 +1254,17 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
       if (rc) return rc;
       wimg = it.wp;
     }
+  }
+  if (it.kind == MUNIT_PREP_WINOGRAD) {
+    WinoParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
+    q.y_sw = d->Cout; q.y_sh = (long long)d->W * d->Cout; q.y_sb = (long long)d->H * d->W * d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout;
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    q.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+    q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cout / 64;
+    q.act = d->act; q.slope = d->slope;
+    return munit_wino_launch(q, st);
   }
   void* slabs = ws ? reinterpret_cast<char*>(ws) + img_bytes : nullptr;
   const size_t slab_bytes = ws ? ws_bytes - img_bytes : 0;
@@ -1627,8 +1650,13 @@ extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, i
 
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
-  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || (item->kind == MUNIT_PREP_CAST && item->bf16),
+  const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
+  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || (item->kind == MUNIT_PREP_CAST && item->bf16),
                   "conv2d_prepare_weights: bad kind %d", item->kind);
+  MUNIT_CHECK_ARG(!wino || (item->KH == 3 && item->KW == 3 && !item->bf16 &&
+                            (item->kind == MUNIT_PREP_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
+                                                               : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
+                  "conv2d_prepare_weights: Winograd image needs a 3x3 fp32 filter, K %% 8 == 0, N %% 64 == 0");
   MUNIT_CHECK_ARG(item->ps >= 1 && item->KH % item->ps == 0 && item->KW % item->ps == 0, "conv2d_prepare_weights: bad phase count");
   MUNIT_CHECK_ARG(item->kind != MUNIT_PREP_SUBPIXEL || (item->KH == 5 && item->KW == 5), "conv2d_prepare_weights: sub-pixel needs 5x5");
   return launch_prep_one(*item, (hipStream_t)stream);
@@ -1651,6 +1679,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36
     if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile
       return 2.0 * d->Cout * d->B * Ho * Wo * plan_cin4(1, 1, d->KH * d->KW).kpad;
     return cc * d->B * Ho * Wo * d->KH * d->KW;

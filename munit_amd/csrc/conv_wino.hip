@@ -1,0 +1,233 @@
+// Winograd F(2x2, 3x3) convolution for gfx950 on v_mfma_f32_16x16x4_f32: the 3x3 / stride 1 / pad 1 layers with wide
+// channel counts (the residual trunk: 256 -> 256 at H/4 x W/4, 57 % of the step's multiply-accumulates).
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// turns the 36 multiply-accumulates of a tile and channel pair into 16: sixteen independent GEMMs (one per frequency
+// f = 4 fi + fj) of [tiles] x [K] x [N].  Everything stays exact fp32 arithmetic on the matrix pipe; the transforms add
+// and subtract only (the halves live in the weight image).  The reference computes these layers with cuDNN, which picks
+// the same algorithm family for fp32 3x3 convolutions (scripts/networks.py:695-701 -> nn.Conv2d).
+//
+// One block = 8x8 tiles (16x16 output pixels) of one image x 64 output channels x all 16 frequencies, 8 waves:
+//   * wave w owns frequencies 2w, 2w+1: two 64 x 64 accumulator tiles = 128 registers;
+//   * K runs in chunks of 8 channels.  Per chunk a thread (tile, channel) reads its 4x4 patch straight from global
+//     memory (neighbouring tiles overlap: the 4x re-read is served by the vector L1), transforms it in registers and
+//     writes 16 values V[f][tile][k] to LDS; the chunk's transformed weights U[f][n][k] (32 KiB, contiguous in the
+//     prepared image) travel global -> LDS directly (global_load_lds_dwordx4);
+//   * V and U are double buffered (2 x 2 x 32 KiB): one barrier per chunk; waves 0-3 transform the next chunk before
+//     their MFMAs and waves 4-7 after, so that the two waves of a SIMD do not leave the matrix pipe idle together;
+//   * epilogue: the 16 frequency planes meet in LDS (two halves of 32 channels), one thread per (tile, channel) folds
+//     them into the 2x2 pixels, adds bias, applies the activation and stores 128-byte row segments.
+#include "wino.h"
+
+namespace {
+
+constexpr int WT = 64;                 // tiles per block
+constexpr int WNB = 64;                // output channels per block
+constexpr int WK = 8;                  // channels per chunk
+constexpr int VBUF = 16 * WT * WK;     // floats per V buffer (32 KiB)
+constexpr int UBUF = 16 * WNB * WK;    // floats per U buffer (32 KiB)
+constexpr int MLD = 36;                // row stride of the epilogue's M[f][tile][32] planes: 4*36 = 16 (mod 64) banks
+constexpr int WINO_SMEM = 16 * WT * MLD;   // 147 456 B; the operand buffers need 131 072
+static_assert(WINO_SMEM >= 2 * VBUF + 2 * UBUF, "operand buffers must fit");
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// none / ReLU / LeakyReLU (tanh layers have 3 output channels and never come here)
+__device__ inline float wino_act(float v, int act, float slope) {
+  return act == MUNIT_ACT_NONE ? v : (v > 0.f ? v : (act == MUNIT_ACT_RELU ? 0.f : v * slope));
+}
+
+template <bool REFLECT>
+__global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[WINO_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware order (blocks b and b+8 share an XCD): every XCD gets one contiguous run of blocks, so the N-blocks of a
+  // tile block and neighbouring tile blocks (shared halo) meet in one L2
+  int blk = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blk & 7, idx = blk >> 3;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n_blk = blk % p.NB;
+  int m_blk = blk / p.NB;
+  const int btx = m_blk % p.btw; m_blk /= p.btw;
+  const int bty = m_blk % p.bth;
+  const int b = m_blk / p.bth;
+
+  // ---- loader: thread = (tile tl, channel ch of the chunk) ----
+  const int tl = tid >> 3, ch = tid & 7;
+  const int gy = min(bty * 8 + (tl >> 3), p.th - 1), gx = min(btx * 8 + (tl & 7), p.tw - 1);   // clamped: stores are predicated
+  // byte offsets of the 4x4 patch (channel ch of chunk 0) for buffer loads; zero padding = an offset past the buffer,
+  // which the load returns as 0
+  unsigned off[16];
+  {
+    int ro[4], co[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ih = 2 * gy - 1 + i, iw = 2 * gx - 1 + i;
+      if (REFLECT) {
+        ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
+        iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+      }
+      ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W * p.K : -1;
+      co[i] = (unsigned)iw < (unsigned)p.W ? iw * p.K + ch : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) off[i * 4 + j] = (ro[i] >= 0 && co[j] >= 0) ? (unsigned)(ro[i] + co[j]) * 4u : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  float d[16];
+  auto load_raw = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, off[q], c * (WK * 4), 0));
+  };
+  // V[f][tile][slot pair]: pair ch>>1 of tile tl sits at slot (ch>>1) ^ (2 * ((tl>>3)&1))  (see the fragment reads)
+  const int vpos = tl * 8 + ((((ch >> 1) ^ (((tl >> 3) & 1) << 1)) << 1) | (ch & 1));
+  auto transform_store = [&](int buf) {
+    float u[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // B^T d
+      u[0 + j] = d[0 + j] - d[8 + j];
+      u[4 + j] = d[4 + j] + d[8 + j];
+      u[8 + j] = d[8 + j] - d[4 + j];
+      u[12 + j] = d[4 + j] - d[12 + j];
+    }
+    float* V = smem + buf * VBUF + vpos;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (.) B
+      V[(i * 4 + 0) * 512] = u[i * 4 + 0] - u[i * 4 + 2];
+      V[(i * 4 + 1) * 512] = u[i * 4 + 1] + u[i * 4 + 2];
+      V[(i * 4 + 2) * 512] = u[i * 4 + 2] - u[i * 4 + 1];
+      V[(i * 4 + 3) * 512] = u[i * 4 + 1] - u[i * 4 + 3];
+    }
+  };
+  // U chunk c of this N-block: 32 KiB contiguous = 32 wave-loads of 1 KiB
+  const float* const ug = p.u + (long long)n_blk * UBUF + lane * 4;
+  const long long u_chunk = (long long)p.NB * UBUF;
+  auto dma_u = [&](int c, int buf) {
+    const float* g = ug + c * u_chunk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int seg = q * 8 + wave;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + seg * 256),
+                                       (__attribute__((address_space(3))) void*)(smem + 2 * VBUF + buf * UBUF + seg * 256), 16, 0, 0);
+    }
+  };
+
+  // ---- MFMA: wave owns frequencies 2*wave, 2*wave+1 ----
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[fq][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment of row r = lane & 15 (+16 per tile), k pair kq = lane >> 4: slot kq ^ (2 * ((r >> 3) & 1)); rows 16 apart
+  // share the swizzle.  A half-wave's ds_read_b64 then covers 16 rows x 2 distinct slots = 64 distinct banks.
+  const int fpos = (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) << 1);
+  auto compute = [&](int buf, int fq) {
+    const float* Vf = smem + buf * VBUF + (wave * 2 + fq) * 512 + fpos;
+    const float* Uf = smem + 2 * VBUF + buf * UBUF + (wave * 2 + fq) * 512 + fpos;
+    f32x2 a[4], bb[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bb[nt] = *reinterpret_cast<const f32x2*>(Uf + nt * 128);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x2*>(Vf + mt * 128);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bb[nt][t], acc[fq][mt][nt], 0, 0, 0);
+  };
+
+  const int nc = p.K / WK;
+  load_raw(0);
+  dma_u(0, 0);
+  transform_store(0);
+  if (nc > 1) load_raw(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    // buffers cur^1 are free: every wave finished chunk c-1 before the barrier above
+    if (c + 1 < nc) dma_u(c + 1, cur ^ 1);
+    const bool more = c + 1 < nc;
+    if (more && wave < 4) {
+      transform_store(cur ^ 1);
+      if (c + 2 < nc) load_raw(c + 2);
+    }
+    compute(cur, 0);
+    compute(cur, 1);
+    if (more && wave >= 4) {
+      transform_store(cur ^ 1);
+      if (c + 2 < nc) load_raw(c + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS chunk has landed (the patch loads long since)
+    __syncthreads();
+  }
+
+  // ---- epilogue: M[f][tile][32 channels] planes through LDS, two halves ----
+  const int co = tid & 31;
+  const float slope = p.slope;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)   // C/D map: col = lane & 15, row = 4 * (lane >> 4) + r
+            smem[((wave * 2 + fq) * 64 + mt * 16 + 4 * (lane >> 4) + r) * MLD + ntl * 16 + (lane & 15)] = acc[fq][mt][half * 2 + ntl][r];
+    __syncthreads();
+    const int n = n_blk * 64 + half * 32 + co;
+    const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int t2 = (tid >> 5) + 16 * it;
+      float m[16];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) m[f] = smem[(f * 64 + t2) * MLD + co];
+      float s[8];   // A^T m: rows 0, 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[j] = (m[0 + j] + m[4 + j]) + m[8 + j];
+        s[4 + j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+      }
+      const int ty = bty * 8 + (t2 >> 3), tx = btx * 8 + (t2 & 7);
+      if (ty < p.th && tx < p.tw) {
+        float* yp = p.y + b * p.y_sb + (long long)(2 * ty) * p.y_sh + (long long)(2 * tx) * p.y_sw + n;
+        yp[0] = wino_act(((s[0] + s[1]) + s[2]) + bv, p.act, slope);
+        yp[p.y_sw] = wino_act(((s[1] - s[2]) - s[3]) + bv, p.act, slope);
+        yp[p.y_sh] = wino_act(((s[4] + s[5]) + s[6]) + bv, p.act, slope);
+        yp[p.y_sh + p.y_sw] = wino_act(((s[5] - s[6]) - s[7]) + bv, p.act, slope);
+      }
+    }
+    if (half == 0) __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool munit_wino_ok(int B, int H, int W, int K, int N) {
+  if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD")) return false;
+  return K % 8 == 0 && N % 64 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 &&
+         (long long)B * H * W * K < (1ll << 29) && (long long)B * H * W * N < (1ll << 40);
+}
+
+int munit_wino_launch(const WinoParams& p, hipStream_t st) {
+  const long long blocks = (long long)p.B * p.bth * p.btw * p.NB;
+  MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
+  if (p.reflect) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  MUNIT_CHECK_LAUNCH("conv_wino");
+  return MUNIT_OK;
+}

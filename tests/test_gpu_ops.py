@@ -56,6 +56,12 @@ CONV_CASES = [
     (3, 128, 4, 2, 1, "reflect", 0, "lrelu", 2, 10, 14),
     (3, 32, 5, 1, 2, "zero", 0, "none", 2, 9, 11),
     (32, 3, 5, 1, 2, "reflect", 0, "none", 2, 9, 11),        # 3 output channels, not 7x7: backward-data on that path too
+    # Winograd F(2x2, 3x3) path (conv_wino.hip): partial 8x8-tile blocks, zero and reflect padding, fused activations,
+    # K = 9 chunks of 8, two N-blocks, the smallest extent, and one block-aligned trunk-like shape
+    (64, 128, 3, 1, 1, "zero", 0, "lrelu", 2, 20, 12),
+    (72, 64, 3, 1, 1, "reflect", 0, "relu", 1, 18, 34),
+    (8, 64, 3, 1, 1, "reflect", 0, "none", 3, 2, 2),
+    (128, 256, 3, 1, 1, "reflect", 0, "none", 1, 32, 48),
 ]
 
 

@@ -1261,7 +1261,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.y_sw = d->Cout; q.y_sh = (long long)d->W * d->Cout; q.y_sb = (long long)d->H * d->W * d->Cout;
     q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout;
     q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
-    q.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
     q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cout / 64;
     q.act = d->act; q.slope = d->slope;
     return munit_wino_launch(q, st);
@@ -1353,6 +1353,7 @@ struct DgradPlan {
   bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
   bool bf16s;   // dy (and the weight image) are bf16 in HBM: bf16-storage kernels (direct-to-LDS forms only)
   bool patch;   // folded with at most two padded positions per axis: the LDS-patch form
+  bool wino;    // 3x3 stride-1 pad-1 fp32 layer: Winograd F(2x2, 3x3) with the border fold in the input patch (conv_wino.hip)
   bool cin4;    // three output channels (the image head): dy re-laid with a zero 4th channel, direct-to-LDS 4-channel taps
   size_t wt_bytes, g_bytes, sk_bytes, c4_bytes;
 };
@@ -1401,6 +1402,14 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   }
   pl->patch = pl->folded && d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, reflect) <= 2 &&
               max_fold_cands(d->W, 0, d->pad, reflect) <= 2;
+  pl->wino = wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cout, d->Cin);
+  if (pl->wino) {
+    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = false;
+    pl->wt_bytes = align_up((size_t)wino_image_elems(d->Cout, d->Cin) * 4, 256);
+    pl->g_bytes = 256;
+    pl->sk_bytes = pl->c4_bytes = 0;
+    return MUNIT_OK;
+  }
   // bf16 storage: dy is bf16 (d->out_dtype), dx / the padded-domain buffer g take d->in_dtype.  Only the direct-to-LDS
   // forms exist in this mode: folded layers must be patchable, everything else runs as a plain correlation + fold_kernel
   // (the up-sampling convs then issue all 100 MACs per source pixel: cheap on the bf16 pipe, and no box sum).
@@ -1487,10 +1496,30 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
   float* g = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.wt_bytes);
   const bool direct = pl.direct && add == nullptr;
   if (wt == nullptr) {   // no prepared image from the caller: re-lay the weights into the workspace
-    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_DGRAD, pl.ps, pl.bf16s ? 1 : 0};
+    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD,
+                pl.ps, pl.bf16s ? 1 : 0};
     rc = launch_prep_one(it, st);
     if (rc) return rc;
     wt = it.wp;
+  }
+  if (pl.wino) {
+    WinoParams q{};
+    q.x = dy; q.u = wt; q.bias = nullptr; q.y = dx;
+    q.y_sw = d->Cin; q.y_sh = (long long)d->W * d->Cin; q.y_sb = (long long)d->H * d->W * d->Cin;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cout; q.N = d->Cin;
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cout * 4);
+    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 2 : 1;
+    q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cin / 64;
+    q.act = MUNIT_ACT_NONE; q.slope = 0.f;
+    rc = munit_wino_launch(q, st);
+    if (rc) return rc;
+    if (add != nullptr) {
+      long long n = (long long)d->B * d->H * d->W * d->Cin;
+      int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+      hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, dx, add, n);
+      MUNIT_CHECK_LAUNCH("add_inplace");
+    }
+    return MUNIT_OK;
   }
   {
     // data gradient of a 7x7 conv with 3 input channels (first encoder layers): the padded-domain
@@ -1634,7 +1663,7 @@ extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const 
     DgradPlan pl;
     rc = plan_dgrad(d, &pl);
     if (rc) return rc;
-    it.kind = MUNIT_PREP_DGRAD;
+    it.kind = pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD;
     it.ps = pl.ps;
     it.bf16 = pl.bf16s ? 1 : 0;
   }
@@ -1686,6 +1715,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   }
   DgradPlan pl;
   if (plan_dgrad(d, &pl)) return 0.0;
+  if (pl.wino) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
   if (pl.boxsum) return cc * d->B * ((double)(d->H - 4) * (d->W - 4) + 4.0 * d->W + 4.0 * (d->H - 4)) * d->KH * d->KW;
   if (pl.folded) return cc * d->B * d->H * d->W * d->KH * d->KW;
   if (pl.direct) return cc * d->B * Ho * Wo * d->KH * d->KW;

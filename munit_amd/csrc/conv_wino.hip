@@ -38,8 +38,15 @@ __device__ inline float wino_act(float v, int act, float slope) {
   return act == MUNIT_ACT_NONE ? v : (v > 0.f ? v : (act == MUNIT_ACT_RELU ? 0.f : v * slope));
 }
 
-template <bool REFLECT>
+// MODE 0: reflect padding (forward).  1: zero padding (forward of a zero-padded layer; backward-data of one).
+// 2: backward-data of a reflect-padded layer = zero-padded correlation of dy with the rotated filter + the fold of the
+//    padded border back onto rows / columns 1 and H-2 / W-2.  The fold needs no second pass: the extra term of output
+//    row 1 is dy row 0 under filter row 0, and inside the top tile (output rows 0, 1; patch rows -1 .. 2) filter row 0
+//    meets patch row 3 for output row 1 only -- so patch row 3 += patch row 1 there; mirrored at the bottom (patch row
+//    0 += patch row 2) and along the columns, the corners get the product of both.  Exact: the transform is linear.
+template <int MODE>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
+  constexpr bool REFLECT = MODE == 0;
   __shared__ __attribute__((aligned(16))) float smem[WINO_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +95,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   };
   // V[f][tile][slot pair]: pair ch>>1 of tile tl sits at slot (ch>>1) ^ (2 * ((tl>>3)&1))  (see the fragment reads)
   const int vpos = tl * 8 + ((((ch >> 1) ^ (((tl >> 3) & 1) << 1)) << 1) | (ch & 1));
+  const bool e_top = gy == 0, e_bot = gy == p.th - 1, e_left = gx == 0, e_right = gx == p.tw - 1;
   auto transform_store = [&](int buf) {
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d[12 + j] += e_top ? d[4 + j] : 0.f;
+        d[0 + j] += e_bot ? d[8 + j] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d[i * 4 + 3] += e_left ? d[i * 4 + 1] : 0.f;
+        d[i * 4 + 0] += e_right ? d[i * 4 + 2] : 0.f;
+      }
+    }
     float u[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {   // B^T d
@@ -226,8 +246,9 @@ bool munit_wino_ok(int B, int H, int W, int K, int N) {
 int munit_wino_launch(const WinoParams& p, hipStream_t st) {
   const long long blocks = (long long)p.B * p.bth * p.btw * p.NB;
   MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
-  if (p.reflect) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  if (p.mode == 0) hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  else if (p.mode == 1) hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_wino");
   return MUNIT_OK;
 }

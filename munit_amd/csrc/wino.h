@@ -43,7 +43,7 @@ struct WinoParams {
   long long y_sb, y_sh, y_sw;
   unsigned x_bytes;    // extent of x for the buffer loads
   int B, H, W, K, N;   // output extent = input extent (3x3, stride 1, pad 1)
-  int reflect;         // reflect padding, else zeros
+  int mode;            // 0 reflect padding, 1 zero padding, 2 zero padding + border fold (backward-data of a reflect layer)
   int th, tw;          // 2x2 output tiles per image axis
   int bth, btw;        // 8x8-tile blocks per image axis
   int NB;              // N / 64

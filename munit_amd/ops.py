@@ -26,6 +26,8 @@ PROFILE = None
 # tests/parity.py sets this to a list to record, in call order, the sign pattern (output > 0) behind every ReLU /
 # LeakyReLU of a forward pass, so that the fp64 oracle can take the same branch at every kink.
 MASK_SINK = None
+# likewise for the other kink of the objective: the sign of (input - target) behind every L1 term, in call order
+L1_SINK = None
 # bench.py sets this to {"alg": 0.0, "exec": 0.0} to add up, over one step, the algorithmic FLOPs of every convolution /
 # linear pass (SURVEY.md section 8d's definition) and the FLOPs the kernels actually issue (sub-pixel and box-sum
 # forms execute fewer).
@@ -651,6 +653,8 @@ class _L1Mean(Function):
             raise RuntimeError("munit_amd.l1_mean: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
         if a.dtype != b.dtype:
             raise RuntimeError("munit_amd.l1_mean: dtype mismatch %s vs %s" % (a.dtype, b.dtype))
+        if L1_SINK is not None:
+            L1_SINK.append(a.float() > b.float())
         if a.dim() == 4:
             a, b = nhwc(a), nhwc(b)
             c = a.shape[1]

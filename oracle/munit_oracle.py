@@ -48,8 +48,17 @@ class KinkMasks:
     function (a pre-activation within rounding noise of 0 otherwise switches an upstream gradient element on or
     off).  Values change by at most that noise; the default (None) is the plain activation."""
 
-    def __init__(self, masks):
+    def __init__(self, masks, l1_signs=None):
         self.masks, self.pos = list(masks), 0
+        # the same for the L1 terms of the objective: recorded (input > target) patterns, in call order; None = plain abs
+        self.l1_signs, self.l1_pos = (None if l1_signs is None else list(l1_signs)), 0
+
+    def take_l1(self, d: Tensor) -> Tensor:
+        assert self.l1_pos < len(self.l1_signs), "more L1 terms than recorded sign patterns"
+        m = self.l1_signs[self.l1_pos]
+        self.l1_pos += 1
+        assert tuple(m.shape) == tuple(d.shape), (self.l1_pos, tuple(m.shape), tuple(d.shape))
+        return m
 
     def take(self, x: Tensor) -> Tensor:
         assert self.pos < len(self.masks), "more activations than recorded masks"
@@ -59,7 +68,7 @@ class KinkMasks:
         return m.reshape(x.shape)
 
     def done(self) -> bool:
-        return self.pos == len(self.masks)
+        return self.pos == len(self.masks) and (self.l1_signs is None or self.l1_pos == len(self.l1_signs))
 
 
 KINK_MASKS: Optional[KinkMasks] = None
@@ -270,14 +279,22 @@ def dis_loss_g(sd, pre, fake, hp_dis) -> Tensor:
     return loss
 
 
+def _abs(d: Tensor) -> Tensor:
+    """|d|, or -- under the KinkMasks test hook -- d times the recorded sign (the same value up to twice the rounding
+    noise of an element within that noise of 0, and the recorded branch of the derivative there)."""
+    if KINK_MASKS is not None and KINK_MASKS.l1_signs is not None:
+        return torch.where(KINK_MASKS.take_l1(d), d, -d)
+    return torch.abs(d)
+
+
 def l1(a: Tensor, b: Tensor) -> Tensor:
     """recon_criterion, trainer.py:279-290."""
-    return torch.mean(torch.abs(a - b))
+    return torch.mean(_abs(a - b))
 
 
 def l1_masked(a: Tensor, b: Tensor, mask: Tensor) -> Tensor:
     """recon_criterion_mask, trainer.py:292-305: mean over ALL elements of |(a-b)(1-mask)|."""
-    return torch.mean(torch.abs((a - b) * (1 - mask)))
+    return torch.mean(_abs((a - b) * (1 - mask)))
 
 
 # --------------------------------------------------------------------------------------

@@ -29,7 +29,10 @@ class GradCheck:
     """Gradient tolerance of one iteration vs the fp64 oracle: SURVEY.md section 8c's 1e-2 normalised max error on
     EVERY tensor, with the kinks pinned.
 
-    Why pinning: the network is piecewise linear in ~10^6 places (ReLU / LeakyReLU).  A pre-activation within fp32
+    Why pinning: the objective is piecewise linear in ~10^6 places (ReLU / LeakyReLU, and the |.| of the L1 terms:
+    ops.L1_SINK / KinkMasks.l1_signs pin those the same way -- an element of x_recon - x within rounding noise of 0
+    flips one +-1/N of an L1 gradient, ~1e-4 of every tensor upstream; seen once the Winograd layers raised the forward
+    noise from ~1e-7 to ~1e-6).  A pre-activation within fp32
     rounding noise of 0 takes the other branch in fp64, which switches one element of an upstream gradient on or off;
     in the last style-encoder layer (4x4x256 at the 64x64 test size) a single flip is ~1.6e-2 relative L2 of every
     tensor upstream of x_ab (measured in round 1, tools/diag_grad.py / diag_xab.py; torch's own CPU fp32 run against
@@ -37,15 +40,16 @@ class GradCheck:
     the kernels, and it used to be absorbed by a 5e-2 / 1e-1 per-tensor bound.  Now the HIP forward records the sign
     pattern behind every ReLU / LeakyReLU (ops.MASK_SINK) and the fp64 oracle takes the same branches
     (oracle.KINK_MASKS), so both sides differentiate the same piecewise-linear function and the comparison is tight:
-        pinned:    every tensor <= 5e-3 normalised max AND <= 2e-3 relative L2, median L2 <= 3e-4  (measured on MI355X,
-                   3 iterations at 64x64: worst 1.5e-3 max / 3.7e-4 L2 -- half of SURVEY's 1e-2 is the hard bound)
+        pinned:    every tensor <= 1e-3 normalised max AND <= 2e-4 relative L2, median L2 <= 2e-5  (measured on MI355X with
+                   the Winograd layers: 3 iterations at 64x64 worst 4.8e-6 max / 4.0e-6 L2, median 1.9e-6; one
+                   iteration at 128x128 worst 1.5e-4 / 2.8e-5 -- SURVEY's bound is 1e-2)
         unpinned:  (diagnostic mode, pin_kinks=False) every tensor <= 5e-2 L2 / 1e-1 max, median <= 2e-3, and at
                    most 10 % of the tensors looser than 1e-2 max -- listed by name in the report."""
 
     def __init__(self, pinned=True):
         self.pinned = pinned
         if pinned:
-            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 3e-4, 2e-3, 5e-3
+            self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 2e-5, 2e-4, 1e-3
         else:
             self.L2_MEDIAN, self.L2_HARD, self.MAX_HARD = 2e-3, 5e-2, 1e-1
         self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0
@@ -169,12 +173,13 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
             """run one HIP update with the host RNG at `seed`, recording the ReLU / LeakyReLU sign patterns"""
             torch.manual_seed(seed)
             ops.MASK_SINK = [] if pin_kinks else None
+            ops.L1_SINK = [] if pin_kinks else None
             try:
                 fn()
-                masks = ops.MASK_SINK
+                masks, signs = ops.MASK_SINK, ops.L1_SINK
             finally:
-                ops.MASK_SINK = None
-            return O.KinkMasks([m.cpu() for m in masks]) if pin_kinks else None
+                ops.MASK_SINK = ops.L1_SINK = None
+            return O.KinkMasks([m.cpu() for m in masks], [m.cpu() for m in signs]) if pin_kinks else None
 
         def oracle(fn, masks):
             O.KINK_MASKS = masks
@@ -216,6 +221,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         gc.finish(check)
         rep["grad_nerr"] = max(rep["grad_nerr"], gc.worst_max)
         rep["grad_l2"] = max(rep.get("grad_l2", 0.0), gc.worst_l2)
+        rep["grad_l2_median"] = max(rep.get("grad_l2_median", 0.0), gc.median)
         rep.setdefault("grad_kinks", []).extend(gc.kinks)
         for k, v in orc.losses.items():
             mine = float(getattr(tr, k).detach())
@@ -243,6 +249,6 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         if check:
             assert rep["moment_l2"] <= 2 * gc.L2_HARD, rep["moment_l2"]
             assert rep["weight_abs"] <= 4.0 * hp["lr"], rep["weight_abs"]
-            assert rep["weight_l2"] <= 2e-3, rep["weight_l2"]
+            assert rep["weight_l2"] <= 2e-4, rep["weight_l2"]
     rep["weight_nerr"] = rep["weight_abs"]
     return rep

@@ -50,7 +50,7 @@ def test_resblock_size_accuracy_vs_native():
         dw, _ = ops.conv2d_wgrad_raw(xd, dyd, tuple(w.shape), 1, 1, "reflect", False, want_bias=False)
         errs[mode] = (nerr(y, yr), nerr(dx, xr.grad), nerr(dw, wr.grad))
     for a, b in zip(errs["f32x3"], errs["f32"]):
-        assert a <= max(2.0 * b, 1e-6), errs
+        assert a <= max(2.0 * b, 2e-6), errs     # native = Winograd for this shape now (fwd / dgrad ~7e-7)
     assert max(errs["f32x3"]) <= 5e-6, errs
 
 

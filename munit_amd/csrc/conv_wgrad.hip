@@ -10,6 +10,7 @@
 // in LDS as [pixel][channel]; v_mfma_f32_16x16x4_f32 operands are fetched with ds_read_b128 / b64
 // (one wide read feeds 4 / 2 MFMA tiles, see Frag).
 #include "common.h"
+#include "wino.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1082,11 +1083,17 @@ void plan_subpixel(const munit_conv_desc* d, SubpixelPlan* sp) {
   sp->slab_bytes = std::max(sp->phase.slab_bytes + sp->phase.bias_bytes, sp->frame.slab_bytes + sp->frame.bias_bytes);
 }
 
+// 3x3 / stride 1 / pad 1 fp32 layers with 64-multiples of channels: Winograd backward-weight (conv_wino.hip)
+bool wino_wgrad_layer(const munit_conv_desc* d) {
+  return d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->KH == 3 &&
+         d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && munit_wino_wgrad_ok(d->B, d->H, d->W, d->Cin, d->Cout);
+}
 }  // namespace
 
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
+  if (wino_wgrad_layer(d)) return munit_wino_wgrad_workspace(d->B, d->H, d->W, d->Cin, d->Cout);
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, Ho);
   if (subpixel_wgrad_ok(d)) {
     SubpixelPlan sp;
@@ -1108,6 +1115,7 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   int Ho, Wo;
   if (pass != MUNIT_PASS_WGRAD || munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
   const double cc = 2.0 * d->Cin * d->Cout;
+  if (wino_wgrad_layer(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return cc * d->B * Ho * Wo * d->KH * d->KW;
   if (subpixel_wgrad_ok(d))   // 4 phase gradients over the interior source pixels + the 25-tap frame
     return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
@@ -1127,6 +1135,9 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (wino_wgrad_layer(d))
+    return munit_wino_wgrad(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), dw, db, beta, d->B, d->H, d->W,
+                            d->Cin, d->Cout, d->pad_mode == MUNIT_PAD_REFLECT, ws, st);
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD"))
   {
     MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32, "conv2d_wgrad: the 3-channel image head has an fp32 dy");

@@ -19,6 +19,7 @@
 //   * epilogue: the 16 frequency planes meet in LDS (two halves of 32 channels), one thread per (tile, channel) folds
 //     them into the 2x2 pixels, adds bias, applies the activation and stores 128-byte row segments.
 #include "wino.h"
+#include <algorithm>
 
 namespace {
 
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, off[q], c * (WK * 4), 0));
   };
-  // V[f][tile][slot pair]: pair ch>>1 of tile tl sits at slot (ch>>1) ^ (2 * ((tl>>3)&1))  (see the fragment reads)
-  const int vpos = tl * 8 + ((((ch >> 1) ^ (((tl >> 3) & 1) << 1)) << 1) | (ch & 1));
+  // V[f][tile][slot pair]: pair ch>>1 of tile tl sits at slot (ch>>1) ^ (2 * ((tl>>3)&1)) ^ (tl>>4)  (see the fragment reads)
+  const int vpos = tl * 8 + ((((ch >> 1) ^ (((tl >> 3) & 1) << 1) ^ ((tl >> 4) & 3)) << 1) | (ch & 1));
   const bool e_top = gy == 0, e_bot = gy == p.th - 1, e_left = gx == 0, e_right = gx == p.tw - 1;
   auto transform_store = [&](int buf) {
     if constexpr (MODE == 2) {
@@ -147,17 +148,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[fq][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragment of row r = lane & 15 (+16 per tile), k pair kq = lane >> 4: slot kq ^ (2 * ((r >> 3) & 1)); rows 16 apart
-  // share the swizzle.  A half-wave's ds_read_b64 then covers 16 rows x 2 distinct slots = 64 distinct banks.
-  const int fpos = (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) << 1);
+  // fragment of row r = lane & 15 of 16-row tile mt, k pair kq = lane >> 4: slot kq ^ (2 * ((r >> 3) & 1)) ^ mt.  A
+  // half-wave's ds_read_b64 (banks mod 64) then covers 16 rows x 2 slots = 64 distinct banks; the mt term keeps the four
+  // reads of a fragment set from being a constant apart, or the compiler fuses them into ds_read2st64_b64, which banks
+  // mod 32 in 16-lane groups (2-way conflicts here: measured 36 % of the LDS cycles) and moves half the bytes per clock.
+  int fpos[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) fpos[mt] = mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
   auto compute = [&](int buf, int fq) {
-    const float* Vf = smem + buf * VBUF + (wave * 2 + fq) * 512 + fpos;
-    const float* Uf = smem + 2 * VBUF + buf * UBUF + (wave * 2 + fq) * 512 + fpos;
+    const float* Vf = smem + buf * VBUF;
+    const float* Uf = smem + 2 * VBUF + buf * UBUF;
     f32x2 a[4], bb[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bb[nt] = *reinterpret_cast<const f32x2*>(Uf + nt * 128);
+    for (int nt = 0; nt < 4; ++nt) {
+      int o = (wave * 2 + fq) * 512 + fpos[nt];
+      asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
+      bb[nt] = *reinterpret_cast<const f32x2*>(Uf + o);
+    }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x2*>(Vf + mt * 128);
+    for (int mt = 0; mt < 4; ++mt) {
+      int o = (wave * 2 + fq) * 512 + fpos[mt];
+      asm("" : "+v"(o));
+      a[mt] = *reinterpret_cast<const f32x2*>(Vf + o);
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -176,20 +189,38 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int cur = c & 1;
-    // buffers cur^1 are free: every wave finished chunk c-1 before the barrier above
-    if (c + 1 < nc) dma_u(c + 1, cur ^ 1);
+    // buffers cur^1 are free: every wave finished chunk c-1 before the barrier above.  Waves 0-3 transform first -- before
+    // the chunk's direct-to-LDS loads are issued, so that the wait for their patch registers (loaded an iteration ago)
+    // does not also wait for those -- and waves 4-7 after their MFMAs.
+    // WINO_ABL_*: timing-only ablation builds (`make alt ALTFLAGS=-DWINO_ABL_NORAW`; the results are wrong)
     const bool more = c + 1 < nc;
-    if (more && wave < 4) {
-      transform_store(cur ^ 1);
-      if (c + 2 < nc) load_raw(c + 2);
-    }
+#ifndef WINO_ABL_NOXFORM
+    if (more && wave < 4) transform_store(cur ^ 1);
+#endif
+#ifndef WINO_ABL_NODMA
+    if (more) dma_u(c + 1, cur ^ 1);
+#endif
+#ifndef WINO_ABL_NORAW
+    if (wave < 4 && c + 2 < nc) load_raw(c + 2);
+#endif
     compute(cur, 0);
     compute(cur, 1);
     if (more && wave >= 4) {
+#ifndef WINO_ABL_NOXFORM
       transform_store(cur ^ 1);
+#endif
+#ifndef WINO_ABL_NORAW
       if (c + 2 < nc) load_raw(c + 2);
+#endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS chunk has landed (the patch loads long since)
+    // the direct-to-LDS chunk must have landed before the barrier publishes it; the 16 patch loads of chunk c+2 were
+    // issued after it (loads return in order) and may stay in flight -- waves 4-7 issued them a moment ago
+#ifdef WINO_ABL_NORAW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
   }
 
@@ -235,7 +266,280 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward-weight.  S[f][co][ci] = sum over tiles of E[f][tile][co] * V[f][tile][ci] with E = A dY A^T (the 2x2 tile of
+// dy spread to 4x4) and V = B^T d B (the forward's input transform): sixteen GEMMs contracting over the tiles, 16
+// products per tile and channel pair instead of 36; dw = G^T S G afterwards.  One block = 64 output x 64 input channels x
+// 16 frequencies over a slice of the tile range (split-K: the slices' partial S go to slabs, wino_wgrad_reduce_kernel
+// adds them and applies G).  Chunk = 8 tiles: wave w loads tile w of the chunk, lane = channel (256-byte rows of x and
+// dy, all addressing on the scalar unit), transforms in registers and writes E / V as [f][tile pair][channel][2] so that
+// the MFMA fragments (channel rows, 4 tile pairs deep) are conflict-free ds_read_b64.  Same accumulator layout, double
+// buffering, one barrier per chunk and early / late transform split as the forward kernel.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WG_PLANE = 4 * 64 * 2;        // floats per frequency plane: [tile pair 4][channel 64][2]
+constexpr int WG_BUF = 16 * WG_PLANE;       // floats per operand buffer (32 KiB)
+
+__global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * WG_BUF];   // E0 E1 V0 V1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk = blockIdx.x;
+  const int cib = blk % p.CB; blk /= p.CB;
+  const int cob = blk % p.NB;
+  const int split = blk / p.NB;
+  const int c_begin = split * p.cps;
+  const int total_chunks = (p.tiles + 7) >> 3;
+  const int nc = min(p.cps, total_chunks - c_begin);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const unsigned xlane = (unsigned)(cib * 64 + lane) * 4u, ylane = (unsigned)(cob * 64 + lane) * 4u;
+  const bool want_db = p.db_part != nullptr && cib == 0;
+
+  float d[16], g[4];
+  float dbs = 0.f;
+  // tile `wave` of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit)
+  auto load_raw = [&](int c) {
+    const int t = (c_begin + c) * 8 + wave;
+    if (t < p.tiles) {
+      const int tx = t % p.tw, r = t / p.tw, ty = r % p.th, b = r / p.th;
+      int ro[4], co[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ih = 2 * ty - 1 + i, iw = 2 * tx - 1 + i;
+        if (p.reflect) {
+          ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
+          iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+        }
+        ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
+        co[i] = (unsigned)iw < (unsigned)p.W ? iw : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ro[i] >= 0 && co[j] >= 0)
+            d[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, xlane, (ro[i] + co[j]) * p.Cin * 4, 0));
+          else
+            d[i * 4 + j] = 0.f;
+        }
+      const int y0 = ((b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4;
+      g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
+      g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + p.Cout * 4, 0));
+      g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + p.W * p.Cout * 4, 0));
+      g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + (p.W + 1) * p.Cout * 4, 0));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) d[q] = 0.f;
+      g[0] = g[1] = g[2] = g[3] = 0.f;
+    }
+  };
+  // plane position of (tile pair kq = wave >> 1, channel lane, element wave & 1); odd pairs swap the two 16-channel
+  // halves of every 32 so that the half-wave fragment reads below (pairs {0,1} or {2,3}) cover all 64 banks
+  const int wpos = ((wave >> 1) * 64 + (lane ^ (((wave >> 1) & 1) << 4))) * 2 + (wave & 1);
+  auto transform_store = [&](int buf) {
+    if (want_db) dbs += (g[0] + g[1]) + (g[2] + g[3]);
+    float* E = smem + buf * WG_BUF + wpos;
+    float* V = smem + (2 + buf) * WG_BUF + wpos;
+    {  // E = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+      const float r[4][2] = {{g[0], g[1]}, {g[0] + g[2], g[1] + g[3]}, {g[0] - g[2], g[1] - g[3]}, {-g[2], -g[3]}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        E[(i * 4 + 0) * WG_PLANE] = r[i][0];
+        E[(i * 4 + 1) * WG_PLANE] = r[i][0] + r[i][1];
+        E[(i * 4 + 2) * WG_PLANE] = r[i][0] - r[i][1];
+        E[(i * 4 + 3) * WG_PLANE] = -r[i][1];
+      }
+    }
+    float u[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // B^T d
+      u[0 + j] = d[0 + j] - d[8 + j];
+      u[4 + j] = d[4 + j] + d[8 + j];
+      u[8 + j] = d[8 + j] - d[4 + j];
+      u[12 + j] = d[4 + j] - d[12 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (.) B
+      V[(i * 4 + 0) * WG_PLANE] = u[i * 4 + 0] - u[i * 4 + 2];
+      V[(i * 4 + 1) * WG_PLANE] = u[i * 4 + 1] + u[i * 4 + 2];
+      V[(i * 4 + 2) * WG_PLANE] = u[i * 4 + 2] - u[i * 4 + 1];
+      V[(i * 4 + 3) * WG_PLANE] = u[i * 4 + 1] - u[i * 4 + 3];
+    }
+  };
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[fq][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment: channel row r = lane & 15 of 16-channel tile mt, tile pair kq = lane >> 4
+  int fpos[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) fpos[mt] = ((lane >> 4) * 64 + ((mt * 16 + (lane & 15)) ^ (((lane >> 4) & 1) << 4))) * 2;
+  auto compute = [&](int buf, int fq) {
+    const float* Ef = smem + buf * WG_BUF;
+    const float* Vf = smem + (2 + buf) * WG_BUF;
+    f32x2 a[4], bb[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      int o = (wave * 2 + fq) * WG_PLANE + fpos[nt];
+      asm("" : "+v"(o));   // keeps every fragment read a ds_read_b64 of its own (see the forward kernel)
+      bb[nt] = *reinterpret_cast<const f32x2*>(Vf + o);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      int o = (wave * 2 + fq) * WG_PLANE + fpos[mt];
+      asm("" : "+v"(o));
+      a[mt] = *reinterpret_cast<const f32x2*>(Ef + o);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bb[nt][t], acc[fq][mt][nt], 0, 0, 0);
+  };
+
+  if (nc > 0) {
+    load_raw(0);
+    transform_store(0);
+    if (nc > 1) load_raw(1);
+  }
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int cur = c & 1;
+    const bool more = c + 1 < nc;
+    if (more && wave < 4) {
+      transform_store(cur ^ 1);
+      if (c + 2 < nc) load_raw(c + 2);
+    }
+    compute(cur, 0);
+    compute(cur, 1);
+    if (more && wave >= 4) {
+      transform_store(cur ^ 1);
+      if (c + 2 < nc) load_raw(c + 2);
+    }
+    __syncthreads();
+  }
+
+  // ---- partial S -> slab[split][f][co][ci] (C/D map: row = co = 4 * (lane >> 4) + r, col = ci = lane & 15) ----
+  float* const sl = p.slab + (long long)split * 16 * p.Cout * p.Cin;
+#pragma unroll
+  for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sl[((long long)(wave * 2 + fq) * p.Cout + cob * 64 + mt * 16 + 4 * (lane >> 4) + r) * p.Cin + cib * 64 + nt * 16 + (lane & 15)] =
+              acc[fq][mt][nt][r];
+  if (want_db) {   // bias: the 8 waves hold the sums of their tiles for channel `lane`
+    smem[wave * 64 + lane] = dbs;
+    __syncthreads();
+    if (wave == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += smem[w * 64 + lane];
+      p.db_part[split * p.Cout + cob * 64 + lane] = s;
+    }
+  }
+}
+
+// dw[co][r][s][ci] = beta * dw + (G^T S G)[r][s],  S = sum over splits; thread = (co, ci), ci fastest.  The last blocks add
+// up the bias partials.
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ db_part, float* __restrict__ dw,
+                                         float* __restrict__ db, int Cout, int Cin, int ksplit, float beta, int pair_blocks) {
+  if ((int)blockIdx.x >= pair_blocks) {
+    const int co = (blockIdx.x - pair_blocks) * blockDim.x + threadIdx.x;
+    if (co < Cout) {
+      float s = 0.f;
+      for (int k = 0; k < ksplit; ++k) s += db_part[k * Cout + co];
+      db[co] = beta == 0.f ? s : beta * db[co] + s;
+    }
+    return;
+  }
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Cout * Cin) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  const long long plane = (long long)Cout * Cin;
+  float S[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f) S[f] = 0.f;
+  for (int k = 0; k < ksplit; ++k) {
+    const float* sp = slab + (long long)k * 16 * plane + idx;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) S[f] += sp[f * plane];
+  }
+  // G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+  float t[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float h = 0.5f * (S[4 + j] + S[8 + j]), m = 0.5f * (S[4 + j] - S[8 + j]);
+    t[0][j] = S[j] + h;
+    t[1][j] = m;
+    t[2][j] = h + S[12 + j];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float h = 0.5f * (t[r][1] + t[r][2]), m = 0.5f * (t[r][1] - t[r][2]);
+    const float v[3] = {t[r][0] + h, m, h + t[r][3]};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float* o = dw + (((long long)co * 3 + r) * 3 + s) * Cin + ci;
+      *o = beta == 0.f ? v[s] : beta * *o + v[s];
+    }
+  }
+}
+
 }  // namespace
+
+bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
+  if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD") || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD_WGRAD")) return false;
+  return Cin % 64 == 0 && Cout % 64 == 0 && H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 &&
+         (long long)B * H * W * std::max(Cin, Cout) < (1ll << 29);
+}
+
+int munit_wino_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  const int chunks = cdiv((long long)B * (H / 2) * (W / 2), 8);
+  const int pairs = (Cin / 64) * (Cout / 64);
+  int ksplit = std::max(1, std::min(chunks, cdiv(256, pairs)));   // one block per CU where the tile range allows
+  const int cps = cdiv(chunks, ksplit);
+  return cdiv(chunks, cps);
+}
+
+size_t munit_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
+  const size_t k = (size_t)munit_wino_wgrad_splits(B, H, W, Cin, Cout);
+  return align_up(k * 16 * Cin * Cout * sizeof(float), 256) + align_up(k * Cout * sizeof(float), 256);
+}
+
+int munit_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float beta, int B, int H, int W, int Cin, int Cout,
+                     int reflect, void* ws, hipStream_t st) {
+  WinoWgradParams p{};
+  p.x = x; p.dy = dy;
+  p.ksplit = munit_wino_wgrad_splits(B, H, W, Cin, Cout);
+  p.slab = reinterpret_cast<float*>(ws);
+  float* db_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((size_t)p.ksplit * 16 * Cin * Cout * sizeof(float), 256));
+  p.db_part = db != nullptr ? db_part : nullptr;
+  p.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4); p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * 4);
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.reflect = reflect;
+  p.th = H / 2; p.tw = W / 2; p.tiles = B * p.th * p.tw;
+  p.cps = cdiv(cdiv(p.tiles, 8), p.ksplit);
+  p.CB = Cin / 64; p.NB = Cout / 64;
+  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(p.CB * p.NB * p.ksplit)), dim3(512), 0, st, p);
+  MUNIT_CHECK_LAUNCH("conv_wino_wgrad");
+  const int pair_blocks = cdiv((long long)Cout * Cin, 256);
+  const int bias_blocks = db != nullptr ? cdiv(Cout, 256) : 0;
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + bias_blocks)), dim3(256), 0, st, p.slab, db_part, dw, db,
+                     Cout, Cin, p.ksplit, beta, pair_blocks);
+  MUNIT_CHECK_LAUNCH("wino_wgrad_reduce");
+  return MUNIT_OK;
+}
 
 bool munit_wino_ok(int B, int H, int W, int K, int N) {
   if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD")) return false;

@@ -5,7 +5,7 @@
 // Transformed weight image of one layer (MUNIT_PREP_WINOGRAD / _WINOGRAD_DGRAD), as the kernel's direct-to-LDS loads
 // want it:  U[c = K/8][nb = N/64][f = 16][n = 64][8]  floats, where K is the contraction channel (forward: Cin;
 // backward-data: Cout), N the produced channel, f = 4*fi + fj the frequency of U = G g G^T, and the 8 channels of a
-// chunk sit in the row as 4 pairs with pair q at slot q ^ (2 * ((n >> 3) & 1)) -- the bank swizzle of the kernel's
+// chunk sit in the row as 4 pairs with pair q at slot q ^ (2 * ((n >> 3) & 1)) ^ ((n >> 4) & 3) -- the bank swizzle of the kernel's
 // ds_read_b64 fragments.  Backward-data multiplies by the filter rotated by 180 degrees with the channel roles swapped.
 __host__ __device__ inline long long wino_image_elems(int K, int N) { return 16ll * K * N; }
 
@@ -16,7 +16,7 @@ __device__ inline float wino_weight_elem(const float* __restrict__ w, int Cout, 
   const int kp = (int)(i & 7), n = (int)((i >> 3) & 63), f = (int)((i >> 9) & 15);
   const long long rest = i >> 13;
   const int nb = (int)(rest % NB), c = (int)(rest / NB);
-  const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1);
+  const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1) ^ ((n >> 4) & 3);
   const int k = c * 8 + q * 2 + (kp & 1), no = nb * 64 + n;
   float g[3][3];
 #pragma unroll
@@ -54,3 +54,23 @@ struct WinoParams {
 // shapes the kernel takes (conv_wino.hip)
 bool munit_wino_ok(int B, int H, int W, int K, int N);
 int munit_wino_launch(const WinoParams& p, hipStream_t st);
+
+// ---- backward-weight: dg = G^T [ sum_tiles (A dY A^T) . (B^T d B) ] G  (conv_wino.hip) ----
+struct WinoWgradParams {
+  const float* x;      // [B][H][W][Cin]
+  const float* dy;     // [B][H][W][Cout]
+  float* slab;         // partial sums S[split][f = 16][Cout][Cin]
+  float* db_part;      // [split][Cout] partial bias gradients, or null
+  unsigned x_bytes, dy_bytes;
+  int B, H, W, Cin, Cout;
+  int reflect;
+  int th, tw, tiles;   // 2x2 output tiles per image axis, in total
+  int cps;             // chunks (of 8 tiles) per split
+  int CB, NB, ksplit;  // Cin / 64, Cout / 64, splits of the tile range
+};
+bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout);
+// splits of the tile range for this shape, and the workspace (slabs + bias partials) they need
+int munit_wino_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+size_t munit_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
+int munit_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float beta, int B, int H, int W, int Cin, int Cout,
+                     int reflect, void* ws, hipStream_t st);

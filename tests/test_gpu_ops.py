@@ -62,6 +62,8 @@ CONV_CASES = [
     (72, 64, 3, 1, 1, "reflect", 0, "relu", 1, 18, 34),
     (8, 64, 3, 1, 1, "reflect", 0, "none", 3, 2, 2),
     (128, 256, 3, 1, 1, "reflect", 0, "none", 1, 32, 48),
+    (64, 64, 3, 1, 1, "reflect", 0, "none", 1, 2, 2),       # one tile: the backward-weight chunk is 7/8 empty
+    (64, 192, 3, 1, 1, "zero", 0, "none", 3, 6, 10),        # 45 tiles: ragged last chunk, zero padding, three N-blocks
 ]
 
 

@@ -16,7 +16,8 @@ prev = None
 for cin in (32, 64, 128, 256, 512, 1024):
     x = torch.randn(8, cin, 64, 64, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(256, cin, 3, 3, generator=g) * 0.03).to(dev).contiguous(memory_format=torch.channels_last)
-    us = timeit(lambda: ops.conv2d_fwd_raw(x, w, None, 1, 1, "reflect", False, "none"))
+    w._munit_prep = {}   # prepared weight image kept with the tensor (Winograd U / none for the direct kernel)
+    us = timeit(lambda: ops.conv2d_fwd_raw(x, w, None, 1, 1, "reflect", False, "none", owner=w))
     fl = 2 * 8 * 64 * 64 * 256 * 9 * cin
     kt = 9 * cin // 32
     extra = "" if prev is None else "  slope %.2f us/K-tile -> %.1f TFLOP/s in-loop" % ((us - prev[0]) / (kt - prev[1]), 2 * 8 * 64 * 64 * 256 * 32 / ((us - prev[0]) / (kt - prev[1])) / 1e6)

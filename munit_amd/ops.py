@@ -21,7 +21,7 @@ from ._lib import ACT, COMPUTE, PAD, ConvDesc
 
 _ws_cache = {}
 # bench.py sets this to a list to time every forward-conv launch with HIP events on the launch stream:
-# entries are (kernel variant tag, algorithmic FLOPs, start event, end event).
+# entries are (kernel variant tag, algorithmic FLOPs, executed FLOPs, start event, end event).
 PROFILE = None
 # tests/parity.py sets this to a list to record, in call order, the sign pattern (output > 0) behind every ReLU /
 # LeakyReLU of a forward pass, so that the fp64 oracle can take the same branch at every kink.
@@ -168,6 +168,8 @@ def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none
         pl.tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
     elif cout <= 4:
         pl.tag = "conv_patch_fwd_kernel"
+    elif pl.prep_sig[0][1] == 4:               # MUNIT_PREP_WINOGRAD: the forward runs conv_wino.hip
+        pl.tag = "conv_wino_kernel<fwd>"
     pl.flop = 2.0 * b * pl.ho * pl.wo * cout * kh * kw * cin        # algorithmic, the same for all three passes
     pl.flop_exec = tuple(lib.munit_conv2d_executed_flops(pl.ref, k) for k in range(3))
     _plans[key] = pl
@@ -291,7 +293,7 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
                                                  ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
         if PROFILE is not None:
             e1.record()
-            PROFILE.append((pl.tag, pl.flop, e0, e1))
+            PROFILE.append((pl.tag, pl.flop, pl.flop_exec[0], e0, e1))
         _count(pl, 0)
     if MASK_SINK is not None and act in ("relu", "lrelu"):
         MASK_SINK.append(y > 0)

@@ -875,6 +875,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) return 4 * wino_image_elems(it.Cin, it.Cout);
   return cc * it.KH * it.KW;
 }
 
@@ -888,6 +889,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
       it.wp[i] = wino_weight_elem(it.w, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
+    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) it.wp[i] = wino_subpixel_weight_elem(it.w, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
@@ -1188,6 +1190,11 @@ bool wino_geometry_ok(const munit_conv_desc* d) {
          d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH;
 }
 bool wino_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
+// the four 3x3 phase convs of a sub-pixel up-sampling layer (over the SOURCE image) through the Winograd kernel
+bool subpixel_wino_ok(const munit_conv_desc* d) {
+  return subpixel_ok(d) && d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 &&
+         d->act != MUNIT_ACT_TANH && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout);
+}
 
 // forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
 munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* wp) {
@@ -1195,7 +1202,7 @@ munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* w
   const bool small = munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD");
   if (small) return it;
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
-  if (subpixel_ok(d)) it.kind = MUNIT_PREP_SUBPIXEL;
+  if (subpixel_ok(d)) it.kind = subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
   else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
   else if (it.bf16) it.kind = MUNIT_PREP_CAST;
   return it;
@@ -1296,7 +1303,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     p.Ktot = c.kpad; p.w_row = c.kpad; p.cin4 = 1;
     return launch_igemm<0>(p, 1, st);
   }
-  if (it.kind == MUNIT_PREP_SUBPIXEL) {
+  if (it.kind == MUNIT_PREP_SUBPIXEL || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
     IgemmParams q = p;
@@ -1311,7 +1318,20 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.w_phase = (long long)d->Cout * q.Ktot;
     q.y_phase_row = (long long)Wo * d->Cout;
     q.y_phase_col = d->Cout;
-    rc = launch_igemm<0>(q, 4, st);
+    if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
+      WinoParams wq{};
+      wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
+      wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
+      wq.u_phase = wino_image_elems(d->Cin, d->Cout); wq.y_prow = q.y_phase_row; wq.y_pcol = q.y_phase_col; wq.phases = 4;
+      wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout;
+      wq.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
+      wq.mode = 1;
+      wq.th = d->H / 2; wq.tw = d->W / 2; wq.bth = cdiv(wq.th, 8); wq.btw = cdiv(wq.tw, 8); wq.NB = d->Cout / 64;
+      wq.act = d->act; wq.slope = d->slope;
+      rc = munit_wino_launch(wq, st);
+    } else {
+      rc = launch_igemm<0>(q, 4, st);
+    }
     if (rc) return rc;
     p.frame = 1;
     p.M = d->B * (4 * Wo + 4 * (Ho - 4));
@@ -1680,7 +1700,10 @@ extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, i
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
   const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
-  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || (item->kind == MUNIT_PREP_CAST && item->bf16),
+  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
+  MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
+                  "conv2d_prepare_weights: sub-pixel Winograd image needs a 5x5 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
+  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || (item->kind == MUNIT_PREP_CAST && item->bf16),
                   "conv2d_prepare_weights: bad kind %d", item->kind);
   MUNIT_CHECK_ARG(!wino || (item->KH == 3 && item->KW == 3 && !item->bf16 &&
                             (item->kind == MUNIT_PREP_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
@@ -1707,6 +1730,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
+    if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36
     if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile

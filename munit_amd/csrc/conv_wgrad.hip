@@ -1073,6 +1073,7 @@ bool subpixel_wgrad_ok(const munit_conv_desc* d) {
 struct SubpixelPlan {
   WgradPlan phase, frame;
   size_t dwc_bytes, slab_bytes;
+  bool wino;   // the four phase gradients (3x3 VALID over the interior source pixels) through the Winograd kernel
 };
 void plan_subpixel(const munit_conv_desc* d, SubpixelPlan* sp) {
   const bool aligned = d->Cin % 4 == 0;
@@ -1081,6 +1082,12 @@ void plan_subpixel(const munit_conv_desc* d, SubpixelPlan* sp) {
   plan_launch(d->B * (4 * Wo + 4 * (Ho - 4)), 25 * d->Cin, d->Cout, aligned, &sp->frame);
   sp->dwc_bytes = align_up((size_t)4 * d->Cout * 9 * d->Cin * sizeof(float), 256);
   sp->slab_bytes = std::max(sp->phase.slab_bytes + sp->phase.bias_bytes, sp->frame.slab_bytes + sp->frame.bias_bytes);
+  sp->wino = d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->H >= 4 &&
+             d->W >= 4 && munit_wino_wgrad_ok(d->B, d->H, d->W, d->Cin, d->Cout) &&
+             (long long)d->B * 4 * d->H * d->W * d->Cout < (1ll << 29);
+  if (sp->wino)
+    sp->slab_bytes = std::max(sp->slab_bytes, munit_wino_wgrad_workspace((long long)d->B * ((d->H - 2) / 2) * ((d->W - 2) / 2),
+                                                                            d->Cin, d->Cout, 4));
 }
 
 // 3x3 / stride 1 / pad 1 fp32 layers with 64-multiples of channels: Winograd backward-weight (conv_wino.hip)
@@ -1093,7 +1100,7 @@ bool wino_wgrad_layer(const munit_conv_desc* d) {
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
-  if (wino_wgrad_layer(d)) return munit_wino_wgrad_workspace(d->B, d->H, d->W, d->Cin, d->Cout);
+  if (wino_wgrad_layer(d)) return munit_wino_wgrad_workspace((long long)d->B * (d->H / 2) * (d->W / 2), d->Cin, d->Cout, 1);
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, Ho);
   if (subpixel_wgrad_ok(d)) {
     SubpixelPlan sp;
@@ -1117,8 +1124,11 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   const double cc = 2.0 * d->Cin * d->Cout;
   if (wino_wgrad_layer(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return cc * d->B * Ho * Wo * d->KH * d->KW;
-  if (subpixel_wgrad_ok(d))   // 4 phase gradients over the interior source pixels + the 25-tap frame
-    return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+  if (subpixel_wgrad_ok(d)) {  // 4 phase gradients over the interior source pixels + the 25-tap frame
+    SubpixelPlan sp;
+    plan_subpixel(d, &sp);
+    return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * (sp.wino ? 4 : 9) + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+  }
   if (cin3_padded_ok(d)) return 2.0 * 4 * d->Cout * d->B * Ho * Wo * d->KH * d->KW;   // zero 4th input channel
   return cc * d->B * Ho * Wo * d->KH * d->KW;
 }
@@ -1135,9 +1145,16 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (wino_wgrad_layer(d))
-    return munit_wino_wgrad(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(dy), dw, db, beta, d->B, d->H, d->W,
-                            d->Cin, d->Cout, d->pad_mode == MUNIT_PAD_REFLECT, ws, st);
+  if (wino_wgrad_layer(d)) {
+    WinoWgradParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4); q.dy_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cout * 4);
+    q.dy_sw = d->Cout; q.dy_sh = (long long)d->W * d->Cout; q.dy_sb = (long long)d->H * d->W * d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
+    q.reflect = d->pad_mode == MUNIT_PAD_REFLECT; q.xo = -1;
+    q.th = d->H / 2; q.tw = d->W / 2; q.phases = 1;
+    return munit_wino_wgrad_launch(q, dw, 0, db, beta, beta, ws, st);
+  }
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD"))
   {
     MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32, "conv2d_wgrad: the 3-channel image head has an fp32 dy");
@@ -1168,7 +1185,19 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     f.M = d->B * (4 * Wo + 4 * (Ho - 4));
     rc = run_wgrad(f, sp.frame, aligned, dw, db, beta, beta, slabs, st);
     if (rc) return rc;
-    for (int ph = 0; ph < 4; ++ph) {
+    if (sp.wino) {
+      WinoWgradParams q{};
+      q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);
+      q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4); q.dy_bytes = (unsigned)((size_t)d->B * Ho * Wo * d->Cout * 4);
+      q.dy_sw = 2 * d->Cout; q.dy_sh = (long long)2 * Wo * d->Cout; q.dy_sb = (long long)Ho * Wo * d->Cout;
+      q.dy_off = ((long long)2 * Wo + 2) * d->Cout; q.dy_prow = (long long)Wo * d->Cout; q.dy_pcol = d->Cout;
+      q.B = d->B; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
+      q.reflect = 0; q.xo = 0;                    // interior source pixels i = oh + 1: taps oh .. oh + 2, a VALID gather
+      q.th = (d->H - 2) / 2; q.tw = (d->W - 2) / 2; q.phases = 4;
+      rc = munit_wino_wgrad_launch(q, dwc, (long long)d->Cout * 9 * d->Cin, db, 0.0f, 1.0f, slabs, st);
+      if (rc) return rc;
+    }
+    for (int ph = 0; ph < 4 && !sp.wino; ++ph) {
       const int a = ph >> 1, b = ph & 1;
       WgradParams q = p;
       q.ups = 0; q.Hu = d->H; q.Wu = d->W;

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     }
   };
   // U chunk c of this N-block: 32 KiB contiguous = 32 wave-loads of 1 KiB
-  const float* const ug = p.u + (long long)n_blk * UBUF + lane * 4;
+  const int phase = blockIdx.y;
+  const float* const ug = p.u + phase * p.u_phase + (long long)n_blk * UBUF + lane * 4;
   const long long u_chunk = (long long)p.NB * UBUF;
   auto dma_u = [&](int c, int buf) {
     const float* g = ug + c * u_chunk;
@@ -155,29 +156,40 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   int fpos[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) fpos[mt] = mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
-  auto compute = [&](int buf, int fq) {
+  // both frequencies' fragments are read up front (16 ds_read_b64 in flight under the first MFMAs) -- WINO_SPLIT_READS
+  // restores the read-8 / multiply-32 / read-8 / multiply-32 order for A/B timing
+  auto compute = [&](int buf) {
     const float* Vf = smem + buf * VBUF;
     const float* Uf = smem + 2 * VBUF + buf * UBUF;
-    f32x2 a[4], bb[4];
+    f32x2 a[2][4], bb[2][4];
+    auto reads = [&](int fq) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      int o = (wave * 2 + fq) * 512 + fpos[nt];
-      asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
-      bb[nt] = *reinterpret_cast<const f32x2*>(Uf + o);
-    }
+      for (int nt = 0; nt < 4; ++nt) {
+        int o = (wave * 2 + fq) * 512 + fpos[nt];
+        asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
+        bb[fq][nt] = *reinterpret_cast<const f32x2*>(Uf + o);
+      }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      int o = (wave * 2 + fq) * 512 + fpos[mt];
-      asm("" : "+v"(o));
-      a[mt] = *reinterpret_cast<const f32x2*>(Vf + o);
-    }
+      for (int mt = 0; mt < 4; ++mt) {
+        int o = (wave * 2 + fq) * 512 + fpos[mt];
+        asm("" : "+v"(o));
+        a[fq][mt] = *reinterpret_cast<const f32x2*>(Vf + o);
+      }
+    };
+    auto mults = [&](int fq) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bb[nt][t], acc[fq][mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 4; ++nt)
+            acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fq][mt][t], bb[fq][nt][t], acc[fq][mt][nt], 0, 0, 0);
+    };
+#ifdef WINO_SPLIT_READS
+    reads(0); mults(0); reads(1); mults(1);
+#else
+    reads(0); reads(1); mults(0); mults(1);
+#endif
   };
 
   const int nc = p.K / WK;
@@ -194,18 +206,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     // does not also wait for those -- and waves 4-7 after their MFMAs.
     // WINO_ABL_*: timing-only ablation builds (`make alt ALTFLAGS=-DWINO_ABL_NORAW`; the results are wrong)
     const bool more = c + 1 < nc;
+#ifdef WINO_NO_STAGGER
+    const bool early = true;
+#else
+    const bool early = wave < 4;
+#endif
 #ifndef WINO_ABL_NOXFORM
-    if (more && wave < 4) transform_store(cur ^ 1);
+    if (more && early) transform_store(cur ^ 1);
 #endif
 #ifndef WINO_ABL_NODMA
     if (more) dma_u(c + 1, cur ^ 1);
 #endif
 #ifndef WINO_ABL_NORAW
-    if (wave < 4 && c + 2 < nc) load_raw(c + 2);
+    if (early && c + 2 < nc) load_raw(c + 2);
 #endif
-    compute(cur, 0);
-    compute(cur, 1);
-    if (more && wave >= 4) {
+    compute(cur);
+    if (more && !early) {
 #ifndef WINO_ABL_NOXFORM
       transform_store(cur ^ 1);
 #endif
@@ -255,7 +271,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
       }
       const int ty = bty * 8 + (t2 >> 3), tx = btx * 8 + (t2 & 7);
       if (ty < p.th && tx < p.tw) {
-        float* yp = p.y + b * p.y_sb + (long long)(2 * ty) * p.y_sh + (long long)(2 * tx) * p.y_sw + n;
+        float* yp = p.y + (phase >> 1) * p.y_prow + (phase & 1) * p.y_pcol + b * p.y_sb + (long long)(2 * ty) * p.y_sh +
+                    (long long)(2 * tx) * p.y_sw + n;
         yp[0] = wino_act(((s[0] + s[1]) + s[2]) + bv, p.act, slope);
         yp[p.y_sw] = wino_act(((s[1] - s[2]) - s[3]) + bv, p.act, slope);
         yp[p.y_sh] = wino_act(((s[4] + s[5]) + s[6]) + bv, p.act, slope);
@@ -288,6 +305,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   const int cib = blk % p.CB; blk /= p.CB;
   const int cob = blk % p.NB;
   const int split = blk / p.NB;
+  const int phase = blockIdx.y;
   const int c_begin = split * p.cps;
   const int total_chunks = (p.tiles + 7) >> 3;
   const int nc = min(p.cps, total_chunks - c_begin);
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
       int ro[4], co[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int ih = 2 * ty - 1 + i, iw = 2 * tx - 1 + i;
+        int ih = 2 * ty + p.xo + i, iw = 2 * tx + p.xo + i;
         if (p.reflect) {
           ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
           iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
@@ -324,11 +342,12 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
           else
             d[i * 4 + j] = 0.f;
         }
-      const int y0 = ((b * p.H + 2 * ty) * p.W + 2 * tx) * p.Cout * 4;
+      const int sw = (int)p.dy_sw * 4, sh = (int)p.dy_sh * 4;
+      const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
       g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
-      g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + p.Cout * 4, 0));
-      g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + p.W * p.Cout * 4, 0));
-      g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + (p.W + 1) * p.Cout * 4, 0));
+      g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
+      g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
+      g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) d[q] = 0.f;
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   }
 
   // ---- partial S -> slab[split][f][co][ci] (C/D map: row = co = 4 * (lane >> 4) + r, col = ci = lane & 15) ----
-  float* const sl = p.slab + (long long)split * 16 * p.Cout * p.Cin;
+  float* const sl = p.slab + ((long long)phase * p.ksplit + split) * 16 * p.Cout * p.Cin;
 #pragma unroll
   for (int fq = 0; fq < 2; ++fq)
 #pragma unroll
@@ -446,7 +465,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += smem[w * 64 + lane];
-      p.db_part[split * p.Cout + cob * 64 + lane] = s;
+      p.db_part[(phase * p.ksplit + split) * p.Cout + cob * 64 + lane] = s;
     }
   }
 }
@@ -454,16 +473,19 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
 // dw[co][r][s][ci] = beta * dw + (G^T S G)[r][s],  S = sum over splits; thread = (co, ci), ci fastest.  The last blocks add
 // up the bias partials.
 __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ db_part, float* __restrict__ dw,
-                                         float* __restrict__ db, int Cout, int Cin, int ksplit, float beta, int pair_blocks) {
-  if ((int)blockIdx.x >= pair_blocks) {
+                                         long long dw_phase, float* __restrict__ db, int Cout, int Cin, int ksplit, float beta,
+                                         float beta_b, int pair_blocks) {
+  if ((int)blockIdx.x >= pair_blocks) {   // bias: all phases and splits, phase-0 blocks only
     const int co = (blockIdx.x - pair_blocks) * blockDim.x + threadIdx.x;
-    if (co < Cout) {
+    if (co < Cout && blockIdx.y == 0) {
       float s = 0.f;
-      for (int k = 0; k < ksplit; ++k) s += db_part[k * Cout + co];
-      db[co] = beta == 0.f ? s : beta * db[co] + s;
+      for (int k = 0; k < ksplit * (int)gridDim.y; ++k) s += db_part[k * Cout + co];
+      db[co] = beta_b == 0.f ? s : beta_b * db[co] + s;
     }
     return;
   }
+  slab += (long long)blockIdx.y * ksplit * 16 * Cout * Cin;
+  dw += blockIdx.y * dw_phase;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Cout * Cin) return;
   const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
@@ -505,38 +527,36 @@ bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
          (long long)B * H * W * std::max(Cin, Cout) < (1ll << 29);
 }
 
-int munit_wino_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
-  const int chunks = cdiv((long long)B * (H / 2) * (W / 2), 8);
-  const int pairs = (Cin / 64) * (Cout / 64);
+int munit_wino_wgrad_splits(long long tiles, int Cin, int Cout, int phases) {
+  const int chunks = cdiv(tiles, 8);
+  const int pairs = (Cin / 64) * (Cout / 64) * std::max(1, phases);
   int ksplit = std::max(1, std::min(chunks, cdiv(256, pairs)));   // one block per CU where the tile range allows
   const int cps = cdiv(chunks, ksplit);
   return cdiv(chunks, cps);
 }
 
-size_t munit_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
-  const size_t k = (size_t)munit_wino_wgrad_splits(B, H, W, Cin, Cout);
+size_t munit_wino_wgrad_workspace(long long tiles, int Cin, int Cout, int phases) {
+  const size_t k = (size_t)munit_wino_wgrad_splits(tiles, Cin, Cout, phases) * std::max(1, phases);
   return align_up(k * 16 * Cin * Cout * sizeof(float), 256) + align_up(k * Cout * sizeof(float), 256);
 }
 
-int munit_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float beta, int B, int H, int W, int Cin, int Cout,
-                     int reflect, void* ws, hipStream_t st) {
-  WinoWgradParams p{};
-  p.x = x; p.dy = dy;
-  p.ksplit = munit_wino_wgrad_splits(B, H, W, Cin, Cout);
-  p.slab = reinterpret_cast<float*>(ws);
-  float* db_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align_up((size_t)p.ksplit * 16 * Cin * Cout * sizeof(float), 256));
-  p.db_part = db != nullptr ? db_part : nullptr;
-  p.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4); p.dy_bytes = (unsigned)((size_t)B * H * W * Cout * 4);
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.reflect = reflect;
-  p.th = H / 2; p.tw = W / 2; p.tiles = B * p.th * p.tw;
+int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, float* db, float beta, float beta_b, void* ws,
+                            hipStream_t st) {
+  p.phases = std::max(1, p.phases);
+  p.tiles = p.B * p.th * p.tw;
+  p.ksplit = munit_wino_wgrad_splits(p.tiles, p.Cin, p.Cout, p.phases);
   p.cps = cdiv(cdiv(p.tiles, 8), p.ksplit);
-  p.CB = Cin / 64; p.NB = Cout / 64;
-  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(p.CB * p.NB * p.ksplit)), dim3(512), 0, st, p);
+  p.CB = p.Cin / 64; p.NB = p.Cout / 64;
+  p.slab = reinterpret_cast<float*>(ws);
+  float* db_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                            align_up((size_t)p.ksplit * p.phases * 16 * p.Cin * p.Cout * sizeof(float), 256));
+  p.db_part = db != nullptr ? db_part : nullptr;
+  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(p.CB * p.NB * p.ksplit), (unsigned)p.phases), dim3(512), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_wino_wgrad");
-  const int pair_blocks = cdiv((long long)Cout * Cin, 256);
-  const int bias_blocks = db != nullptr ? cdiv(Cout, 256) : 0;
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + bias_blocks)), dim3(256), 0, st, p.slab, db_part, dw, db,
-                     Cout, Cin, p.ksplit, beta, pair_blocks);
+  const int pair_blocks = cdiv((long long)p.Cout * p.Cin, 256);
+  const int bias_blocks = db != nullptr ? cdiv(p.Cout, 256) : 0;
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + bias_blocks), (unsigned)p.phases), dim3(256), 0, st, p.slab,
+                     db_part, dw, dw_phase, db, p.Cout, p.Cin, p.ksplit, beta, beta_b, pair_blocks);
   MUNIT_CHECK_LAUNCH("wino_wgrad_reduce");
   return MUNIT_OK;
 }
@@ -550,9 +570,10 @@ bool munit_wino_ok(int B, int H, int W, int K, int N) {
 int munit_wino_launch(const WinoParams& p, hipStream_t st) {
   const long long blocks = (long long)p.B * p.bth * p.btw * p.NB;
   MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
-  if (p.mode == 0) hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)blocks), dim3(512), 0, st, p);
-  else if (p.mode == 1) hipLaunchKernelGGL(conv_wino_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, st, p);
+  const dim3 grid((unsigned)blocks, (unsigned)std::max(1, p.phases));
+  if (p.mode == 0) hipLaunchKernelGGL(conv_wino_kernel<0>, grid, dim3(512), 0, st, p);
+  else if (p.mode == 1) hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(512), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_wino");
   return MUNIT_OK;
 }

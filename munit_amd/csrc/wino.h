@@ -9,22 +9,8 @@
 // ds_read_b64 fragments.  Backward-data multiplies by the filter rotated by 180 degrees with the channel roles swapped.
 __host__ __device__ inline long long wino_image_elems(int K, int N) { return 16ll * K * N; }
 
-// element i of the image from the OHWI fp32 weights w[Cout][3][3][Cin]
-__device__ inline float wino_weight_elem(const float* __restrict__ w, int Cout, int Cin, bool dgrad, long long i) {
-  const int N = dgrad ? Cin : Cout;
-  const int NB = N >> 6;
-  const int kp = (int)(i & 7), n = (int)((i >> 3) & 63), f = (int)((i >> 9) & 15);
-  const long long rest = i >> 13;
-  const int nb = (int)(rest % NB), c = (int)(rest / NB);
-  const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1) ^ ((n >> 4) & 3);
-  const int k = c * 8 + q * 2 + (kp & 1), no = nb * 64 + n;
-  float g[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      g[r][s] = dgrad ? w[(((long long)k * 3 + (2 - r)) * 3 + (2 - s)) * Cin + no] : w[(((long long)no * 3 + r) * 3 + s) * Cin + k];
-  // row fi of G g (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]), then column fj of (.) G^T
+// (G g G^T)[fi][fj], G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+__device__ inline float wino_u_of_g(const float (&g)[3][3], int f) {
   const int fi = f >> 2, fj = f & 3;
   float t[3];
 #pragma unroll
@@ -35,12 +21,66 @@ __device__ inline float wino_weight_elem(const float* __restrict__ w, int Cout, 
   return fj == 0 ? t[0] : fj == 1 ? 0.5f * ((t[0] + t[2]) + t[1]) : fj == 2 ? 0.5f * ((t[0] + t[2]) - t[1]) : t[2];
 }
 
+// image position i -> frequency f, contraction channel k, produced channel no (N = produced channels)
+__device__ inline void wino_image_index(long long i, int N, int& f, int& k, int& no) {
+  const int NB = N >> 6;
+  const int kp = (int)(i & 7), n = (int)((i >> 3) & 63);
+  f = (int)((i >> 9) & 15);
+  const long long rest = i >> 13;
+  const int nb = (int)(rest % NB), c = (int)(rest / NB);
+  const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1) ^ ((n >> 4) & 3);
+  k = c * 8 + q * 2 + (kp & 1);
+  no = nb * 64 + n;
+}
+
+// element i of the image from the OHWI fp32 weights w[Cout][3][3][Cin]
+__device__ inline float wino_weight_elem(const float* __restrict__ w, int Cout, int Cin, bool dgrad, long long i) {
+  int f, k, no;
+  wino_image_index(i, dgrad ? Cin : Cout, f, k, no);
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      g[r][s] = dgrad ? w[(((long long)k * 3 + (2 - r)) * 3 + (2 - s)) * Cin + no] : w[(((long long)no * 3 + r) * 3 + s) * Cin + k];
+  return wino_u_of_g(g, f);
+}
+
+// Sub-pixel form of nearest-x2-upsample + 5x5 conv (conv_igemm.hip, prep_subpixel_elem): phase (a, b) of the output is a
+// 3x3 conv over the source with the 5 filter rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (columns
+// likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin].
+__device__ inline float wino_subpixel_weight_elem(const float* __restrict__ w, int Cout, int Cin, long long i) {
+  const long long per = wino_image_elems(Cin, Cout);
+  const int ph = (int)(i / per), a = ph >> 1, b = ph & 1;
+  int f, k, no;
+  wino_image_index(i - ph * per, Cout, f, k, no);
+  float g[3][3];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
+      const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
+      const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
+      const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
+      float s = 0.f;
+      for (int kh = h0; kh < h0 + hn; ++kh)
+        for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)no * 5 + kh) * 5 + kw) * Cin + k];
+      g[dh][dw] = s;
+    }
+  return wino_u_of_g(g, f);
+}
+
 struct WinoParams {
   const float* x;      // NHWC input [B][H][W][K]
   const float* u;      // transformed weights (see above)
   const float* bias;   // [N] or null
   float* y;            // output pixel (b, oh, ow) channel n at y[b*y_sb + oh*y_sh + ow*y_sw + n]
   long long y_sb, y_sh, y_sw;
+  // gridDim.y launch phases (sub-pixel up-sampling conv: 4): phase ph = 2a + b reads u + ph * u_phase and writes to
+  // y + a * y_prow + b * y_pcol
+  long long u_phase, y_prow, y_pcol;
+  int phases;
   unsigned x_bytes;    // extent of x for the buffer loads
   int B, H, W, K, N;   // output extent = input extent (3x3, stride 1, pad 1)
   int mode;            // 0 reflect padding, 1 zero padding, 2 zero padding + border fold (backward-data of a reflect layer)
@@ -58,19 +98,25 @@ int munit_wino_launch(const WinoParams& p, hipStream_t st);
 // ---- backward-weight: dg = G^T [ sum_tiles (A dY A^T) . (B^T d B) ] G  (conv_wino.hip) ----
 struct WinoWgradParams {
   const float* x;      // [B][H][W][Cin]
-  const float* dy;     // [B][H][W][Cout]
-  float* slab;         // partial sums S[split][f = 16][Cout][Cin]
-  float* db_part;      // [split][Cout] partial bias gradients, or null
+  const float* dy;     // output gradient; pixel (b, oh, ow) of the tiled region at dy_off + b*dy_sb + oh*dy_sh + ow*dy_sw
+  float* slab;         // partial sums S[phase][split][f = 16][Cout][Cin]
+  float* db_part;      // [phase][split][Cout] partial bias gradients, or null
   unsigned x_bytes, dy_bytes;
+  long long dy_sb, dy_sh, dy_sw, dy_off;   // elements
+  long long dy_prow, dy_pcol;              // launch phase ph = 2a + b (gridDim.y) adds a*dy_prow + b*dy_pcol to dy_off
   int B, H, W, Cin, Cout;
-  int reflect;
-  int th, tw, tiles;   // 2x2 output tiles per image axis, in total
+  int reflect;         // padding of x when the patch leaves the image (xo = -1): reflect, else zeros
+  int xo;              // patch origin: output pixel (oh, ow) reads x rows oh + xo .. oh + xo + 2 (-1: pad 1; 0: VALID)
+  int th, tw, tiles;   // 2x2 output tiles per axis of the tiled region, in total
   int cps;             // chunks (of 8 tiles) per split
   int CB, NB, ksplit;  // Cin / 64, Cout / 64, splits of the tile range
+  int phases;
 };
 bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout);
-// splits of the tile range for this shape, and the workspace (slabs + bias partials) they need
-int munit_wino_wgrad_splits(int B, int H, int W, int Cin, int Cout);
-size_t munit_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
-int munit_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float beta, int B, int H, int W, int Cin, int Cout,
-                     int reflect, void* ws, hipStream_t st);
+// splits of the tile range, and the workspace (slabs + bias partials) for `phases` launch phases over `tiles` tiles
+int munit_wino_wgrad_splits(long long tiles, int Cin, int Cout, int phases);
+size_t munit_wino_wgrad_workspace(long long tiles, int Cin, int Cout, int phases);
+// p: tensors, strides and geometry filled in (x, dy, *_bytes, dy_*, B..Cout, reflect, xo, th, tw, phases); writes
+// dw + ph * dw_phase = beta * (.) + gradient of phase ph ([Cout][3][3][Cin]) and db = beta_b * db + sum over phases
+int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, float* db, float beta, float beta_b, void* ws,
+                            hipStream_t st);

@@ -10,12 +10,16 @@
 //
 // One block = 8x8 tiles (16x16 output pixels) of one image x 64 output channels x all 16 frequencies, 8 waves:
 //   * wave w owns frequencies 2w, 2w+1: two 64 x 64 accumulator tiles = 128 registers;
-//   * K runs in chunks of 8 channels.  Per chunk a thread (tile, channel) reads its 4x4 patch straight from global
-//     memory (neighbouring tiles overlap: the 4x re-read is served by the vector L1), transforms it in registers and
-//     writes 16 values V[f][tile][k] to LDS; the chunk's transformed weights U[f][n][k] (32 KiB, contiguous in the
-//     prepared image) travel global -> LDS directly (global_load_lds_dwordx4);
-//   * V and U are double buffered (2 x 2 x 32 KiB): one barrier per chunk; waves 0-3 transform the next chunk before
-//     their MFMAs and waves 4-7 after, so that the two waves of a SIMD do not leave the matrix pipe idle together;
+//   * K runs in chunks of 8 channels.  Waves 0-3 are the loaders: per chunk a thread (tile, channel pair) reads its 4x4
+//     patch straight from global memory (buffer_load_dwordx2; neighbouring tiles overlap and the 4x re-read is served by
+//     the vector L1; zero padding = an out-of-range offset), transforms it in registers (packed adds) and writes 16
+//     pairs V[f][tile][k, k+1] to LDS.  Waves 4-7 start the chunk's transformed weights U[f][n][k] (32 KiB, contiguous in
+//     the prepared image) global -> LDS directly (global_load_lds_dwordx4) and multiply at once, so the matrix pipe of
+//     every SIMD is fed by its multiply-only wave while its loader wave transforms.  Measured on the trunk layer
+//     (tools/time_conv.py, back-to-back launches): all eight waves loading one channel each, four before and four after
+//     their MFMAs: 203 us; without that stagger 213; this split: 195.  Timing-only ablations of the symmetric form:
+//     without the patch loads 172, without the U loads 182, without loads and transform 167 us.
+//   * V and U are double buffered (2 x 2 x 32 KiB): one barrier per chunk;
 //   * epilogue: the 16 frequency planes meet in LDS (two halves of 32 channels), one thread per (tile, channel) folds
 //     them into the 2x2 pixels, adds bias, applies the activation and stores 128-byte row segments.
 #include "wino.h"
@@ -65,11 +69,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   const int bty = m_blk % p.bth;
   const int b = m_blk / p.bth;
 
-  // ---- loader: thread = (tile tl, channel ch of the chunk) ----
-  const int tl = tid >> 3, ch = tid & 7;
+  // ---- loader (waves 0-3 only): thread = (tile tl, channel pair cp of the chunk); waves 4-7 only multiply ----
+  const bool loader = wave < 4;
+  const int tl = (tid & 255) >> 2, cp = tid & 3;
   const int gy = min(bty * 8 + (tl >> 3), p.th - 1), gx = min(btx * 8 + (tl & 7), p.tw - 1);   // clamped: stores are predicated
-  // byte offsets of the 4x4 patch (channel ch of chunk 0) for buffer loads; zero padding = an offset past the buffer,
-  // which the load returns as 0
   unsigned off[16];
   {
     int ro[4], co[4];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
         iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
       }
       ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W * p.K : -1;
-      co[i] = (unsigned)iw < (unsigned)p.W ? iw * p.K + ch : -1;
+      co[i] = (unsigned)iw < (unsigned)p.W ? iw * p.K + 2 * cp : -1;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -89,28 +92,28 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
       for (int j = 0; j < 4; ++j) off[i * 4 + j] = (ro[i] >= 0 && co[j] >= 0) ? (unsigned)(ro[i] + co[j]) * 4u : 0x80000000u;
   }
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  float d[16];
+  f32x2 d[16];
   auto load_raw = [&](int c) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, off[q], c * (WK * 4), 0));
+    for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, off[q], c * (WK * 4), 0));
   };
-  // V[f][tile][slot pair]: pair ch>>1 of tile tl sits at slot (ch>>1) ^ (2 * ((tl>>3)&1)) ^ (tl>>4)  (see the fragment reads)
-  const int vpos = tl * 8 + ((((ch >> 1) ^ (((tl >> 3) & 1) << 1) ^ ((tl >> 4) & 3)) << 1) | (ch & 1));
+  const int vpos = tl * 8 + ((cp ^ (((tl >> 3) & 1) << 1) ^ ((tl >> 4) & 3)) << 1);
   const bool e_top = gy == 0, e_bot = gy == p.th - 1, e_left = gx == 0, e_right = gx == p.tw - 1;
   auto transform_store = [&](int buf) {
+    const f32x2 z = {0.f, 0.f};
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        d[12 + j] += e_top ? d[4 + j] : 0.f;
-        d[0 + j] += e_bot ? d[8 + j] : 0.f;
+        d[12 + j] += e_top ? d[4 + j] : z;
+        d[0 + j] += e_bot ? d[8 + j] : z;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        d[i * 4 + 3] += e_left ? d[i * 4 + 1] : 0.f;
-        d[i * 4 + 0] += e_right ? d[i * 4 + 2] : 0.f;
+        d[i * 4 + 3] += e_left ? d[i * 4 + 1] : z;
+        d[i * 4 + 0] += e_right ? d[i * 4 + 2] : z;
       }
     }
-    float u[16];
+    f32x2 u[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {   // B^T d
       u[0 + j] = d[0 + j] - d[8 + j];
@@ -121,10 +124,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     float* V = smem + buf * VBUF + vpos;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // (.) B
-      V[(i * 4 + 0) * 512] = u[i * 4 + 0] - u[i * 4 + 2];
-      V[(i * 4 + 1) * 512] = u[i * 4 + 1] + u[i * 4 + 2];
-      V[(i * 4 + 2) * 512] = u[i * 4 + 2] - u[i * 4 + 1];
-      V[(i * 4 + 3) * 512] = u[i * 4 + 1] - u[i * 4 + 3];
+      *reinterpret_cast<f32x2*>(V + (i * 4 + 0) * 512) = u[i * 4 + 0] - u[i * 4 + 2];
+      *reinterpret_cast<f32x2*>(V + (i * 4 + 1) * 512) = u[i * 4 + 1] + u[i * 4 + 2];
+      *reinterpret_cast<f32x2*>(V + (i * 4 + 2) * 512) = u[i * 4 + 2] - u[i * 4 + 1];
+      *reinterpret_cast<f32x2*>(V + (i * 4 + 3) * 512) = u[i * 4 + 1] - u[i * 4 + 3];
     }
   };
   // U chunk c of this N-block: 32 KiB contiguous = 32 wave-loads of 1 KiB
@@ -133,9 +136,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   const long long u_chunk = (long long)p.NB * UBUF;
   auto dma_u = [&](int c, int buf) {
     const float* g = ug + c * u_chunk;
+    if (loader) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int seg = q * 8 + wave;
+    for (int q = 0; q < 8; ++q) {
+      const int seg = q * 4 + (wave - 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + seg * 256),
                                        (__attribute__((address_space(3))) void*)(smem + 2 * VBUF + buf * UBUF + seg * 256), 16, 0, 0);
     }
@@ -156,8 +160,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   int fpos[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) fpos[mt] = mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
-  // both frequencies' fragments are read up front (16 ds_read_b64 in flight under the first MFMAs) -- WINO_SPLIT_READS
-  // restores the read-8 / multiply-32 / read-8 / multiply-32 order for A/B timing
+  // both frequencies' fragments are requested up front (the compiler sinks the second set under the first MFMAs)
   auto compute = [&](int buf) {
     const float* Vf = smem + buf * VBUF;
     const float* Uf = smem + 2 * VBUF + buf * UBUF;
@@ -185,61 +188,32 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           for (int nt = 0; nt < 4; ++nt)
             acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fq][mt][t], bb[fq][nt][t], acc[fq][mt][nt], 0, 0, 0);
     };
-#ifdef WINO_SPLIT_READS
-    reads(0); mults(0); reads(1); mults(1);
-#else
     reads(0); reads(1); mults(0); mults(1);
-#endif
   };
 
   const int nc = p.K / WK;
-  load_raw(0);
+  if (loader) {
+    load_raw(0);
+    transform_store(0);
+    if (nc > 1) load_raw(1);
+  }
   dma_u(0, 0);
-  transform_store(0);
-  if (nc > 1) load_raw(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int cur = c & 1;
-    // buffers cur^1 are free: every wave finished chunk c-1 before the barrier above.  Waves 0-3 transform first -- before
-    // the chunk's direct-to-LDS loads are issued, so that the wait for their patch registers (loaded an iteration ago)
-    // does not also wait for those -- and waves 4-7 after their MFMAs.
-    // WINO_ABL_*: timing-only ablation builds (`make alt ALTFLAGS=-DWINO_ABL_NORAW`; the results are wrong)
     const bool more = c + 1 < nc;
-#ifdef WINO_NO_STAGGER
-    const bool early = true;
-#else
-    const bool early = wave < 4;
-#endif
-#ifndef WINO_ABL_NOXFORM
-    if (more && early) transform_store(cur ^ 1);
-#endif
-#ifndef WINO_ABL_NODMA
-    if (more) dma_u(c + 1, cur ^ 1);
-#endif
-#ifndef WINO_ABL_NORAW
-    if (early && c + 2 < nc) load_raw(c + 2);
-#endif
-    compute(cur);
-    if (more && !early) {
-#ifndef WINO_ABL_NOXFORM
+    // waves 0-3: transform chunk c+1 (its patch registers were loaded an iteration ago), fetch the patches of chunk c+2,
+    // then multiply; waves 4-7: start the direct-to-LDS loads of U(c+1) and multiply at once
+    if (loader && more) {
       transform_store(cur ^ 1);
-#endif
-#ifndef WINO_ABL_NORAW
       if (c + 2 < nc) load_raw(c + 2);
-#endif
     }
-    // the direct-to-LDS chunk must have landed before the barrier publishes it; the 16 patch loads of chunk c+2 were
-    // issued after it (loads return in order) and may stay in flight -- waves 4-7 issued them a moment ago
-#ifdef WINO_ABL_NORAW
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-    if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    if (more) dma_u(c + 1, cur ^ 1);
+    compute(cur);
+    if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // U(c+1) has landed before the barrier publishes it
     __syncthreads();
   }
-
   // ---- epilogue: M[f][tile][32 channels] planes through LDS, two halves ----
   const int co = tid & 31;
   const float slope = p.slope;

@@ -881,22 +881,27 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
 
 // blockIdx.y = item (DEV: table in device memory, one launch re-lays every weight of an optimizer; else the one
 // item passed by value), grid-stride over the item's elements in x
+// loop trips of one image: its elements, or -- Winograd images -- its (k, n) channel pairs (16 elements each)
+__host__ __device__ inline long long prep_trips(const PrepItem& it) {
+  const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
+  return wino ? prep_elems(it) / 16 : prep_elems(it);
+}
 template <bool DEV>
 __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem one) {
   const PrepItem it = DEV ? items[blockIdx.y] : one;
-  const long long total = prep_elems(it);
+  const long long total = prep_trips(it);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
-      it.wp[i] = wino_weight_elem(it.w, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
-    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) it.wp[i] = wino_subpixel_weight_elem(it.w, it.Cout, it.Cin, i);
+      wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
+    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
 }
 
 int launch_prep_one(const PrepItem& it, hipStream_t st) {
-  const long long total = prep_elems(it);
+  const long long total = prep_trips(it);
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(prep_weights_kernel<false>, dim3(blocks), dim3(256), 0, st, nullptr, it);
   MUNIT_CHECK_LAUNCH("prep_weights");

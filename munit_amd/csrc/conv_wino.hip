@@ -266,7 +266,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
 // adds them and applies G).  Chunk = 8 tiles: wave w loads tile w of the chunk, lane = channel (256-byte rows of x and
 // dy, all addressing on the scalar unit), transforms in registers and writes E / V as [f][tile pair][channel][2] so that
 // the MFMA fragments (channel rows, 4 tile pairs deep) are conflict-free ds_read_b64.  Same accumulator layout, double
-// buffering, one barrier per chunk and early / late transform split as the forward kernel.
+// buffering and one barrier per chunk as the forward kernel; all eight waves load and transform here (waves 0-3 before their
+// MFMAs, 4-7 after): giving the loads to four waves of two tiles each, as the forward does, was slower (275 vs 222 us).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WG_PLANE = 4 * 64 * 2;        // floats per frequency plane: [tile pair 4][channel 64][2]
 constexpr int WG_BUF = 16 * WG_PLANE;       // floats per operand buffer (32 KiB)

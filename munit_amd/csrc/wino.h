@@ -21,39 +21,44 @@ __device__ inline float wino_u_of_g(const float (&g)[3][3], int f) {
   return fj == 0 ? t[0] : fj == 1 ? 0.5f * ((t[0] + t[2]) + t[1]) : fj == 2 ? 0.5f * ((t[0] + t[2]) - t[1]) : t[2];
 }
 
-// image position i -> frequency f, contraction channel k, produced channel no (N = produced channels)
-__device__ inline void wino_image_index(long long i, int N, int& f, int& k, int& no) {
+// Work item j of an image = one (contraction channel k, produced channel no) pair, all 16 frequencies: element
+// ((j >> 9) * 16 + f) * 512 + (j & 511) for f = 0..15 (N = produced channels).
+__device__ inline void wino_item_index(long long j, int N, int& k, int& no) {
   const int NB = N >> 6;
-  const int kp = (int)(i & 7), n = (int)((i >> 3) & 63);
-  f = (int)((i >> 9) & 15);
-  const long long rest = i >> 13;
+  const int kp = (int)(j & 7), n = (int)((j >> 3) & 63);
+  const long long rest = j >> 9;
   const int nb = (int)(rest % NB), c = (int)(rest / NB);
   const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1) ^ ((n >> 4) & 3);
   k = c * 8 + q * 2 + (kp & 1);
   no = nb * 64 + n;
 }
+__device__ inline void wino_store_item(float* __restrict__ img, long long j, const float (&g)[3][3]) {
+  float* o = img + (j >> 9) * (16 * 512) + (j & 511);
+#pragma unroll
+  for (int f = 0; f < 16; ++f) o[f * 512] = wino_u_of_g(g, f);
+}
 
-// element i of the image from the OHWI fp32 weights w[Cout][3][3][Cin]
-__device__ inline float wino_weight_elem(const float* __restrict__ w, int Cout, int Cin, bool dgrad, long long i) {
-  int f, k, no;
-  wino_image_index(i, dgrad ? Cin : Cout, f, k, no);
+// item j of the image of the OHWI fp32 weights w[Cout][3][3][Cin]; items = K * N
+__device__ inline void wino_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, bool dgrad, long long j) {
+  int k, no;
+  wino_item_index(j, dgrad ? Cin : Cout, k, no);
   float g[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int s = 0; s < 3; ++s)
       g[r][s] = dgrad ? w[(((long long)k * 3 + (2 - r)) * 3 + (2 - s)) * Cin + no] : w[(((long long)no * 3 + r) * 3 + s) * Cin + k];
-  return wino_u_of_g(g, f);
+  wino_store_item(img, j, g);
 }
 
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv (conv_igemm.hip, prep_subpixel_elem): phase (a, b) of the output is a
 // 3x3 conv over the source with the 5 filter rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (columns
-// likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin].
-__device__ inline float wino_subpixel_weight_elem(const float* __restrict__ w, int Cout, int Cin, long long i) {
-  const long long per = wino_image_elems(Cin, Cout);
-  const int ph = (int)(i / per), a = ph >> 1, b = ph & 1;
-  int f, k, no;
-  wino_image_index(i - ph * per, Cout, f, k, no);
+// likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin]; items = 4 * Cin * Cout.
+__device__ inline void wino_subpixel_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
+  const long long per = (long long)Cin * Cout;
+  const int ph = (int)(j / per), a = ph >> 1, b = ph & 1;
+  int k, no;
+  wino_item_index(j - ph * per, Cout, k, no);
   float g[3][3];
 #pragma unroll
   for (int dh = 0; dh < 3; ++dh)
@@ -68,7 +73,7 @@ __device__ inline float wino_subpixel_weight_elem(const float* __restrict__ w, i
         for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)no * 5 + kh) * 5 + kw) * Cin + k];
       g[dh][dw] = s;
     }
-  return wino_u_of_g(g, f);
+  wino_store_item(img + ph * wino_image_elems(Cin, Cout), j - ph * per, g);
 }
 
 struct WinoParams {

@@ -164,12 +164,12 @@ def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none
         sig.append((which, item.kind, item.ps, item.bf16) if rc == 0 else (which, 0, 0, 0))
     pl.prep_sig = tuple(sig)
     pl.tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if cout <= 64 else 128, "true" if cin % 32 == 0 else "false")
-    if pl.ws_fwd:
+    if pl.prep_sig[0][1] == 4:                 # MUNIT_PREP_WINOGRAD: the forward is one launch of conv_wino.hip
+        pl.tag = "conv_wino_kernel<fwd>"
+    elif pl.ws_fwd:
         pl.tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
     elif cout <= 4:
         pl.tag = "conv_patch_fwd_kernel"
-    elif pl.prep_sig[0][1] == 4:               # MUNIT_PREP_WINOGRAD: the forward runs conv_wino.hip
-        pl.tag = "conv_wino_kernel<fwd>"
     pl.flop = 2.0 * b * pl.ho * pl.wo * cout * kh * kw * cin        # algorithmic, the same for all three passes
     pl.flop_exec = tuple(lib.munit_conv2d_executed_flops(pl.ref, k) for k in range(3))
     _plans[key] = pl

@@ -12,4 +12,4 @@ def fin(self, check=True):
     for r in rows[::max(1, len(rows)//25)]: print("   l2 %.2e max %.2e gmax %.2e %s" % (r[0], r[1], r[3], r[2]))
     return orig_fin(self, check)
 P.GradCheck.add, P.GradCheck.finish = add, fin
-rep = P.run_step_parity(size=64, batch=2, gen_state=1, iters=2, device="cuda:0", check=False)
+rep = P.run_step_parity(size=64, batch=2, gen_state=1, iters=3, device="cuda:0", check=False)

@@ -258,6 +258,19 @@ def test_compute_mode_plumbing_without_gpu():
     # the forward of a bf16-input layer multiplies by a bf16 copy of the weights; backward-data by the bf16 transpose
     assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d), 0) == 128 * 9 * 64 * 2
     assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d), 1) == 128 * 9 * 64 * 2
+    # fp32 3x3 / stride 1 / pad 1 with wide channels: both passes multiply by a Winograd image (16 frequencies per channel pair)
     d32 = _lib.ConvDesc(2, 8, 8, 64, 128, 3, 3, 1, 1, 1, 0, 0, 0.0, 0, 0, 0)
-    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 0) == 0
-    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 1) == 128 * 9 * 64 * 4
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 0) == 16 * 64 * 128 * 4
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(d32), 1) == 16 * 64 * 128 * 4
+    for which, kind in ((0, 4), (1, 5)):      # MUNIT_PREP_WINOGRAD, MUNIT_PREP_WINOGRAD_DGRAD
+        item = _lib.PrepItem()
+        assert lib.munit_conv2d_prep_item(ctypes.byref(d32), which, None, None, ctypes.byref(item)) == 0 and item.kind == kind
+    # odd extent: the direct kernels (forward: the weights as they are; backward-data: their transpose)
+    dodd = _lib.ConvDesc(2, 9, 8, 64, 128, 3, 3, 1, 1, 1, 0, 0, 0.0, 0, 0, 0)
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(dodd), 0) == 0
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(dodd), 1) == 128 * 9 * 64 * 4
+    # nearest-x2 + 5x5 reflect-pad-2: four merged 3x3 phase filters, as Winograd images when the source extent is even
+    dup = _lib.ConvDesc(2, 8, 8, 128, 64, 5, 5, 1, 2, 1, 1, 0, 0.0, 0, 0, 0)
+    item = _lib.PrepItem()
+    assert lib.munit_conv2d_prep_item(ctypes.byref(dup), 0, None, None, ctypes.byref(item)) == 0 and item.kind == 6
+    assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(dup), 0) == 4 * 16 * 128 * 64 * 4

@@ -108,6 +108,11 @@ int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, 
 /* Prepared weight images.  Two passes multiply by a re-laid-out image of the layer's weights: backward-data
  * (flipped / transposed, one slice per stride phase: the autograd transpose of nn.Conv2d, networks.py:691-693) and the
  * sub-pixel forward of the nearest-x2 + 5x5 decoder convs (networks.py:532-546; four merged 3x3 phase kernels).
+ * The fp32 3x3 / stride 1 / pad 1 layers with wide channel counts (the residual blocks, networks.py:603-624) and those
+ * phase kernels run as Winograd F(2x2, 3x3) on the fp32 matrix pipe: their images are U = G g G^T (16 frequencies per
+ * channel pair, laid out for the kernel's direct-to-LDS loads; _WINOGRAD_DGRAD: of the filter rotated by 180 degrees with
+ * the channel roles swapped; _SUBPIXEL_WINOGRAD: of the four merged phase filters).  Same results as the direct form to
+ * fp32 rounding (the algorithm cuDNN uses for the reference's own fp32 3x3 convolutions).
  * Weights change only at optimizer.step() (scripts/trainer.py:252-268), so the caller may keep these images: query
  * the size (0 = the pass uses w as it is), fill a munit_prep_item on the host with munit_conv2d_prep_item, build
  * the image with munit_conv2d_prepare_weights (one layer) or munit_conv2d_prepare_weights_batch (a table of items

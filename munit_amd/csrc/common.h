@@ -88,9 +88,10 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass);
 // conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side
 bool munit_small_fwd_supported(const munit_conv_desc* d);
 bool munit_small_wgrad_supported(const munit_conv_desc* d);
-// x is read as d->in_dtype (fp32 or bf16); y is always fp32 (3 channels)
+// x is read as d->in_dtype (fp32 or bf16); y is always fp32 (3 channels); ws: munit_small_fwd_workspace(d) bytes
+size_t munit_small_fwd_workspace(const munit_conv_desc* d);
 int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* w, const float* bias,
-                    float* y, hipStream_t st);
+                    float* y, void* ws, hipStream_t st);
 size_t munit_small_wgrad_workspace(const munit_conv_desc* d, int Ho);
 // x is read as d->in_dtype; dy (3 channels) is fp32
 int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* dy, float* dw,

@@ -1222,6 +1222,7 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
+  if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return munit_small_fwd_workspace(d);
   if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d)) return img;
   if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
     const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
@@ -1248,7 +1249,12 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
   hipStream_t st = (hipStream_t)stream;
   if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) {
     MUNIT_CHECK_ARG(d->out_dtype == MUNIT_DTYPE_F32, "conv2d_fwd: the 3-channel image head writes fp32");
-    return munit_small_fwd(d, Ho, Wo, x, w, bias, reinterpret_cast<float*>(y), st);
+    const size_t sneed = munit_small_fwd_workspace(d);
+    if (sneed != 0 && (ws == nullptr || ws_bytes < sneed)) {
+      munit_set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, sneed);
+      return MUNIT_ERR_WORKSPACE;
+    }
+    return munit_small_fwd(d, Ho, Wo, x, w, bias, reinterpret_cast<float*>(y), ws, st);
   }
   const size_t need = munit_conv2d_fwd_workspace_bytes(d);
   if (need != 0 && (ws == nullptr || ws_bytes < need)) {
@@ -1381,6 +1387,7 @@ struct DgradPlan {
   bool wino;    // 3x3 stride-1 pad-1 fp32 layer: Winograd F(2x2, 3x3) with the border fold in the input patch (conv_wino.hip)
   bool cin4;    // three output channels (the image head): dy re-laid with a zero 4th channel, direct-to-LDS 4-channel taps
   size_t wt_bytes, g_bytes, sk_bytes, c4_bytes;
+  size_t small_ws;   // small: workspace of the 3-output-channel forward kernel that computes the padded-domain correlation
 };
 // number of padded/up-sampled coordinates folding onto one source coordinate (host mirror of fold_cands)
 int max_fold_cands(int H, int ups, int P, int reflect) {
@@ -1423,6 +1430,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     t.stride = 1; t.pad = pl->TH - 1; t.pad_mode = MUNIT_PAD_ZERO;
     pl->small = !pl->direct && pl->ps == 1 && munit_small_fwd_supported(&t) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_DGRAD");
     if (pl->small) pl->folded = false;
+    pl->small_ws = pl->small ? munit_small_fwd_workspace(&t) : 0;
     if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_FOLD")) pl->folded = false;
   }
   pl->patch = pl->folded && d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, reflect) <= 2 &&
@@ -1432,7 +1440,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = false;
     pl->wt_bytes = align_up((size_t)wino_image_elems(d->Cout, d->Cin) * 4, 256);
     pl->g_bytes = 256;
-    pl->sk_bytes = pl->c4_bytes = 0;
+    pl->sk_bytes = pl->c4_bytes = pl->small_ws = 0;
     return MUNIT_OK;
   }
   // bf16 storage: dy is bf16 (d->out_dtype), dx / the padded-domain buffer g take d->in_dtype.  Only the direct-to-LDS
@@ -1465,7 +1473,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
     pl->sk_bytes = splitk_bytes(d->B * (4 * d->W + 4 * (d->H - 4)), d->Cin, d->KH * d->KW * d->Cout, 1);
     return MUNIT_OK;
   }
-  pl->sk_bytes = (pl->folded || pl->small) ? 0
+  pl->sk_bytes = pl->small ? pl->small_ws : pl->folded ? 0
                  : splitk_bytes(d->B * (pl->Ho + pl->TH - 1) * (pl->Wo + pl->TW - 1), d->Cin,
                                 pl->TH * pl->TW * d->Cout, pl->ps * pl->ps);
   return MUNIT_OK;
@@ -1555,7 +1563,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
     t.in_dtype = d->out_dtype; t.out_dtype = MUNIT_DTYPE_F32;
     if (pl.small) {
       MUNIT_CHECK_ARG(!dx_bf16, "conv2d_dgrad: the 3-channel data gradient is fp32");
-      rc = munit_small_fwd(&t, pl.Hq, pl.Wq, dy_, wt, nullptr, g, st);
+      rc = munit_small_fwd(&t, pl.Hq, pl.Wq, dy_, wt, nullptr, g, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, st);
       if (rc) return rc;
       const int reflect = d->pad_mode == MUNIT_PAD_REFLECT;
       long long total = (long long)d->B * d->H * d->W * d->Cin;

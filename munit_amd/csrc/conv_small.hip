@@ -244,6 +244,153 @@ __global__ __launch_bounds__(256, 2) void conv_head_mfma_kernel(SmallParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward on the vector ALUs with packed FMAs (round 2, replaces the 4x4x1 MFMA form as the default): v_pk_fma_f32 issues
+// two exact fp32 FMAs per lane and cycle -- the same 64 FLOP/clk/SIMD as the fp32 matrix pipe -- and takes a wave-uniform
+// weight pair straight from SGPRs, so three output channels cost no padding at all.  The MFMA form above is bound by its
+// operand traffic (one ds_read_b128 per lane for four 8-cycle MFMAs = the full LDS rate of the CU); here one lane owns
+// two adjacent output pixels and every ds_read_b128 (4 channels of one patch pixel) feeds up to 2 pixels x 3 channels x 4 =
+// 24 FMAs, and the 8 reads of one patch row segment serve all 7 horizontal taps.
+//   per tap and channel c:        (o0, o1)[A] += xA[c] * (w0, w1)[c]     v_pk_fma_f32, xA[c] broadcast by op_sel; same for B
+//   per tap and channel pair:     o2[A] (even, odd partial) += (xA[c], xA[c+1]) * (w2[c], w2[c+1])      same for B
+//   = 12 packed FMAs for the 24 multiply-accumulates of a tap and channel quad: nothing is padded, nothing is moved.
+// Block = 4 waves, tile 16 rows x 32 pixels (wave = 4 rows, lane = pixel pair), 8 input channels per pass; the halo patch
+// of a pass (22 x 38 pixels x 32 B = 26 KiB: four to five blocks per CU cover each other's fills) is laid out
+// [row][channel quad][column parity][column / 2][4] so that the 16 lanes of a row read 256 contiguous bytes (conflict-free)
+// for every tap; fp32 input fills it with global_load_lds_dwordx4.  The weights are re-laid once per call into
+// [pass][kh][quad][kw][12] (38 KiB in the workspace): (w0 w1) pairs of the quad's four channels, then their four w2.
+// ---------------------------------------------------------------------------------------------
+constexpr int HP_TW = 32, HP_TH = 16, HP_K = 7, HP_PW = HP_TW + HP_K - 1, HP_PH = HP_TH + HP_K - 1, HP_CP = 8;
+constexpr int HP_IDX = 20;                                   // (HP_PW + 1) / 2 = 19 column pairs, padded to 20
+constexpr int HP_ROW = (HP_CP / 4) * 2 * HP_IDX * 4;         // floats per patch row: [quad][parity][idx][4] = 320 (1280 B = 5 bank rows)
+constexpr int HP_ITEMS = HP_PH * (HP_CP / 4) * 2 * HP_IDX;   // 16-byte items of the patch: 1760
+
+// wp[((pass * 7 + kh) * 2 + quad) * 7 + kw][12] = (w0 w1)[c0] (w0 w1)[c1] (w0 w1)[c2] (w0 w1)[c3] | w2[c0] w2[c1] w2[c2] w2[c3]
+// for the four input channels c = pass * 8 + quad * 4 + 0..3 of tap (kh, kw); w is [3][7][7][Cin]
+__global__ void head_pk_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin) {
+  const int total = (Cin / HP_CP) * HP_K * 2 * HP_K * 12;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int e = r % 12; r /= 12;
+    const int kw = r % HP_K; r /= HP_K;
+    const int quad = r & 1; r >>= 1;
+    const int kh = r % HP_K;
+    const int pass = r / HP_K;
+    const int co = e < 8 ? (e & 1) : 2, c = e < 8 ? (e >> 1) : e - 8;
+    wp[i] = w[((long long)(co * HP_K + kh) * HP_K + kw) * Cin + pass * HP_CP + quad * 4 + c];
+  }
+}
+
+template <typename XT>
+__global__ __launch_bounds__(256, 4) void conv_head_pk_kernel(SmallParams p, const float* __restrict__ wp) {
+  __shared__ __attribute__((aligned(16))) float patch[HP_PH * HP_ROW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, lr = 4 * wv + (lane >> 4);        // pixel pair (columns 2j, 2j+1) of tile row lr
+  int bid = blockIdx.x;
+  const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
+  const int tile_y = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int ow0 = tile_x * HP_TW, oh0 = tile_y * HP_TH;
+  const XT* xb = reinterpret_cast<const XT*>(p.x) + (long long)b * p.H * p.W * p.Cin;
+
+  // fill items of this thread: item n -> (row, quad, parity, idx); patch column = 2 * idx + parity
+  constexpr int PER = (HP_ITEMS + 255) / 256;   // 7
+  int foff[PER];                                // element offset of the item's 4 channels at pass 0, or -1 (zero)
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int n = (wv + 4 * it) * 64 + lane;
+    int r = n;
+    const int idx = r % HP_IDX; r /= HP_IDX;
+    const int par = r & 1; r >>= 1;
+    const int quad = r & 1;
+    const int row = r >> 1;
+    const int pc = 2 * idx + par;
+    const int ih = map_coord(oh0 + row - p.pad, p.H, p.reflect);
+    const int iw = map_coord(ow0 + pc - p.pad, p.W, p.reflect);
+    foff[it] = (n < HP_ITEMS && pc < HP_PW && ih >= 0 && iw >= 0) ? (ih * p.W + iw) * p.Cin + quad * 4 : -1;
+  }
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 a01 = {0.f, 0.f}, b01 = {0.f, 0.f};   // output channels 0, 1 of pixel A / B
+  f32x2 a2 = {0.f, 0.f}, b2 = {0.f, 0.f};     // output channel 2: partial sums over the even / odd input channels
+  const float* rd = patch + lr * HP_ROW + j * 4;   // + (kh * HP_ROW) + ((quad * 2 + (i & 1)) * HP_IDX + (i >> 1)) * 4
+  const int npass = p.Cin / HP_CP;
+  for (int pass = 0; pass < npass; ++pass) {
+    __syncthreads();
+    if constexpr (sizeof(XT) == 4) {
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int n0 = (wv + 4 * it) * 64;
+        if (n0 < HP_ITEMS) {   // wave-uniform; the last wave-load runs past the patch by 32 items: clipped by the lane test below
+          const void* g = foff[it] >= 0 ? (const void*)(xb + foff[it] + pass * HP_CP) : (const void*)munit_head_zero16;
+          if (n0 + 64 <= HP_ITEMS || n0 + lane < HP_ITEMS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(patch + n0 * 4), 16, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      f32x4 stage[PER];
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (foff[it] >= 0) v = ld4(xb + foff[it] + pass * HP_CP);
+        stage[it] = v;
+      }
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int n = (wv + 4 * it) * 64 + lane;
+        if (n < HP_ITEMS) *reinterpret_cast<f32x4*>(&patch[n * 4]) = stage[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kh = 0; kh < HP_K; ++kh) {
+#pragma unroll
+      for (int quad = 0; quad < 2; ++quad) {
+        f32x4 xs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          xs[i] = *reinterpret_cast<const f32x4*>(rd + kh * HP_ROW + ((quad * 2 + (i & 1)) * HP_IDX + (i >> 1)) * 4);
+        const float* wq = wp + (((pass * HP_K + kh) * 2 + quad) * HP_K) * 12;   // wave-uniform: scalar loads
+#pragma unroll
+        for (int kw = 0; kw < HP_K; ++kw) {
+          const f32x4 xa = xs[kw], xb2 = xs[kw + 1];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x2 w01 = {wq[kw * 12 + 2 * c], wq[kw * 12 + 2 * c + 1]};
+            a01 = __builtin_elementwise_fma(f32x2{xa[c], xa[c]}, w01, a01);
+            b01 = __builtin_elementwise_fma(f32x2{xb2[c], xb2[c]}, w01, b01);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 w2 = {wq[kw * 12 + 8 + 2 * h], wq[kw * 12 + 9 + 2 * h]};
+            a2 = __builtin_elementwise_fma(f32x2{xa[2 * h], xa[2 * h + 1]}, w2, a2);
+            b2 = __builtin_elementwise_fma(f32x2{xb2[2 * h], xb2[2 * h + 1]}, w2, b2);
+          }
+        }
+      }
+    }
+  }
+  const int oh = oh0 + lr, ow = ow0 + 2 * j;
+  if (oh < p.Ho) {
+    const float bias0 = p.bias != nullptr ? p.bias[0] : 0.f, bias1 = p.bias != nullptr ? p.bias[1] : 0.f,
+                bias2 = p.bias != nullptr ? p.bias[2] : 0.f;
+    float* yo = p.y + (((long long)b * p.Ho + oh) * p.Wo + ow) * 3;
+    if (ow < p.Wo) {
+      yo[0] = apply_act(a01[0] + bias0, p.act, p.slope);
+      yo[1] = apply_act(a01[1] + bias1, p.act, p.slope);
+      yo[2] = apply_act((a2[0] + a2[1]) + bias2, p.act, p.slope);
+    }
+    if (ow + 1 < p.Wo) {
+      yo[3] = apply_act(b01[0] + bias0, p.act, p.slope);
+      yo[4] = apply_act(b01[1] + bias1, p.act, p.slope);
+      yo[5] = apply_act((b2[0] + b2[1]) + bias2, p.act, p.slope);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward-weight: channel per lane; unit = (b, band of rows_per_unit output rows, kh, channel group)
 // ---------------------------------------------------------------------------------------------
 template <int CO, int K, typename XT>
@@ -355,12 +502,30 @@ bool munit_small_wgrad_supported(const munit_conv_desc* d) {
   return d->Cout == 3 && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->upsample == 0 && d->Cin % 64 == 0;
 }
 
+size_t munit_small_fwd_workspace(const munit_conv_desc* d) {
+  // packed-FMA head kernel: the re-laid weights [Cin/8][7][2][7][4][4]
+  if (d->Cin % 8 != 0 || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_HEAD_PK")) return 0;
+  return align_up((size_t)(d->Cin / HP_CP) * HP_K * 2 * HP_K * 12 * sizeof(float), 256);
+}
+
 int munit_small_fwd(const munit_conv_desc* d, int Ho, int Wo, const void* x, const float* w, const float* bias,
-                    float* y, hipStream_t st) {
+                    float* y, void* ws, hipStream_t st) {
   SmallParams p{};
   p.x = x; p.w = w; p.bias = bias; p.y = y;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo;
   p.pad = d->pad; p.reflect = d->pad_mode == MUNIT_PAD_REFLECT; p.act = d->act; p.slope = d->slope;
+  if (munit_small_fwd_workspace(d) != 0 && ws != nullptr) {
+    float* wp = reinterpret_cast<float*>(ws);
+    const int total = (d->Cin / HP_CP) * HP_K * 2 * HP_K * 12;
+    hipLaunchKernelGGL(head_pk_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, d->Cin);
+    MUNIT_CHECK_LAUNCH("head_pk_weights");
+    p.tiles_x = cdiv(Wo, HP_TW); p.tiles_y = cdiv(Ho, HP_TH);
+    const long long nb = (long long)d->B * p.tiles_x * p.tiles_y;
+    if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_head_pk_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, p, wp);
+    else hipLaunchKernelGGL((conv_head_pk_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, p, wp);
+    MUNIT_CHECK_LAUNCH("conv_head_pk");
+    return MUNIT_OK;
+  }
   if (d->Cin % 64 == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_HEAD_MFMA")) {
     p.tiles_x = cdiv(Wo, 16); p.tiles_y = cdiv(Ho, 8);
     const long long nb = (long long)d->B * p.tiles_x * p.tiles_y;

@@ -98,7 +98,7 @@ def pmc_traffic_bytes():
                 f = line.split()
                 fetch = float(f[f.index("fetch") + 1])
                 write = float(f[f.index("write") + 1])
-                return (fetch + write) * 1e6, "%s (512-block launches: %.0f MB read + %.0f MB written)" % (PMC_SUMMARY, fetch, write)
+                return int(round((fetch + write) * 1e6)), "%s (512-block launches: %.0f MB read + %.0f MB written)" % (PMC_SUMMARY, fetch, write)
     except ValueError:
         pass
     return None, "dominant kernel not found in %s" % PMC_SUMMARY

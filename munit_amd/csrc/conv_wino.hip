@@ -31,10 +31,10 @@ constexpr int WT = 64;                 // tiles per block
 constexpr int WNB = 64;                // output channels per block
 constexpr int WK = 8;                  // channels per chunk
 constexpr int VBUF = 16 * WT * WK;     // floats per V buffer (32 KiB)
-constexpr int UBUF = 16 * WNB * WK;    // floats per U buffer (32 KiB)
+constexpr int UBUF = 16 * WNB * WK;    // floats of U per chunk and N block (32 KiB)
 constexpr int MLD = 36;                // row stride of the epilogue's M[f][tile][32] planes: 4*36 = 16 (mod 64) banks
-constexpr int WINO_SMEM = 16 * WT * MLD;   // 147 456 B; the operand buffers need 131 072
-static_assert(WINO_SMEM >= 2 * VBUF + 2 * UBUF, "operand buffers must fit");
+constexpr int WINO_SMEM = 16 * WT * MLD;   // 147 456 B (the epilogue's planes); the V buffers need 65 536
+static_assert(WINO_SMEM >= 2 * VBUF, "operand buffers must fit");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -130,19 +130,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
       *reinterpret_cast<f32x2*>(V + (i * 4 + 3) * 512) = u[i * 4 + 1] - u[i * 4 + 3];
     }
   };
-  // U chunk c of this N-block: 32 KiB contiguous = 32 wave-loads of 1 KiB
+  // U: the two frequency planes of a wave are private to it, so they never touch LDS: per chunk the wave reads its
+  // 2 x 64 x 8 weights as four global_load_dwordx4 in fragment order (prepared image: [chunk][N block][f][half][lane][4] --
+  // lane (n, kq) holds (k pair kq of channel n) for the 16-channel tiles 2*half and 2*half+1)
   const int phase = blockIdx.y;
-  const float* const ug = p.u + phase * p.u_phase + (long long)n_blk * UBUF + lane * 4;
-  const long long u_chunk = (long long)p.NB * UBUF;
-  auto dma_u = [&](int c, int buf) {
-    const float* g = ug + c * u_chunk;
-    if (loader) return;
+  const f32x4* const ug = reinterpret_cast<const f32x4*>(p.u + phase * p.u_phase + (long long)n_blk * UBUF) + wave * 2 * 128 + lane;
+  const long long u_chunk = (long long)p.NB * UBUF / 4;   // f32x4 per chunk
+  struct UFrag { f32x4 v[2][2]; };   // [fq][half]
+  auto load_u = [&](int c, UFrag& u) {
+    const f32x4* g = ug + c * u_chunk;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int seg = q * 4 + (wave - 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + seg * 256),
-                                       (__attribute__((address_space(3))) void*)(smem + 2 * VBUF + buf * UBUF + seg * 256), 16, 0, 0);
-    }
+    for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) u.v[fq][h] = g[fq * 128 + h * 64];
   };
 
   // ---- MFMA: wave owns frequencies 2*wave, 2*wave+1 ----
@@ -160,59 +160,63 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   int fpos[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) fpos[mt] = mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
-  // both frequencies' fragments are requested up front (the compiler sinks the second set under the first MFMAs)
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, const UFrag& u) {
     const float* Vf = smem + buf * VBUF;
-    const float* Uf = smem + 2 * VBUF + buf * UBUF;
-    f32x2 a[2][4], bb[2][4];
-    auto reads = [&](int fq) {
+    f32x2 a[2][4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        int o = (wave * 2 + fq) * 512 + fpos[nt];
-        asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
-        bb[fq][nt] = *reinterpret_cast<const f32x2*>(Uf + o);
-      }
+    for (int fq = 0; fq < 2; ++fq)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         int o = (wave * 2 + fq) * 512 + fpos[mt];
-        asm("" : "+v"(o));
+        asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
         a[fq][mt] = *reinterpret_cast<const f32x2*>(Vf + o);
       }
-    };
-    auto mults = [&](int fq) {
+#pragma unroll
+    for (int fq = 0; fq < 2; ++fq)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fq][mt][t], bb[fq][nt][t], acc[fq][mt][nt], 0, 0, 0);
-    };
-    reads(0); reads(1); mults(0); mults(1);
+            acc[fq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fq][mt][t], u.v[fq][nt >> 1][(nt & 1) * 2 + t], acc[fq][mt][nt], 0, 0, 0);
   };
 
+  // One barrier per chunk publishes V(c+1) and frees V(c-1)'s buffer; it is the only synchronisation left.
+  //   loader waves (0-3):     U(c) requested first, consumed after the transform of chunk c+1 (a register set of 16);
+  //   multiplier waves (4-7): U(c+1) requested while chunk c multiplies (two register sets, ping-pong), so they start on
+  //                           the V fragments the moment the barrier opens.
   const int nc = p.K / WK;
   if (loader) {
     load_raw(0);
     transform_store(0);
     if (nc > 1) load_raw(1);
-  }
-  dma_u(0, 0);
-  if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int c = 0; c < nc; ++c) {
-    const int cur = c & 1;
-    const bool more = c + 1 < nc;
-    // waves 0-3: transform chunk c+1 (its patch registers were loaded an iteration ago), fetch the patches of chunk c+2,
-    // then multiply; waves 4-7: start the direct-to-LDS loads of U(c+1) and multiply at once
-    if (loader && more) {
-      transform_store(cur ^ 1);
-      if (c + 2 < nc) load_raw(c + 2);
-    }
-    if (more) dma_u(c + 1, cur ^ 1);
-    compute(cur);
-    if (!loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // U(c+1) has landed before the barrier publishes it
     __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+      const int cur = c & 1;
+      UFrag u;
+      load_u(c, u);
+      if (c + 1 < nc) {
+        transform_store(cur ^ 1);
+        if (c + 2 < nc) load_raw(c + 2);
+      }
+      compute(cur, u);
+      __syncthreads();
+    }
+  } else {
+    UFrag u0, u1;
+    load_u(0, u0);
+    __syncthreads();
+    for (int c = 0; c < nc; c += 2) {
+      if (c + 1 < nc) load_u(c + 1, u1);
+      compute(0, u0);
+      __syncthreads();
+      if (c + 1 < nc) {
+        if (c + 2 < nc) load_u(c + 2, u0);
+        compute(1, u1);
+        __syncthreads();
+      }
+    }
   }
   // ---- epilogue: M[f][tile][32 channels] planes through LDS, two halves ----
   const int co = tid & 31;

@@ -2,11 +2,10 @@
 #pragma once
 #include "common.h"
 
-// Transformed weight image of one layer (MUNIT_PREP_WINOGRAD / _WINOGRAD_DGRAD), as the kernel's direct-to-LDS loads
-// want it:  U[c = K/8][nb = N/64][f = 16][n = 64][8]  floats, where K is the contraction channel (forward: Cin;
-// backward-data: Cout), N the produced channel, f = 4*fi + fj the frequency of U = G g G^T, and the 8 channels of a
-// chunk sit in the row as 4 pairs with pair q at slot q ^ (2 * ((n >> 3) & 1)) ^ ((n >> 4) & 3) -- the bank swizzle of the kernel's
-// ds_read_b64 fragments.  Backward-data multiplies by the filter rotated by 180 degrees with the channel roles swapped.
+// Transformed weight image of one layer (MUNIT_PREP_WINOGRAD / _WINOGRAD_DGRAD), as the kernel's fragment loads want
+// it:  U[c = K/8][nb = N/64][f = 16][512]  floats, where K is the contraction channel (forward: Cin;
+// backward-data: Cout), N the produced channel, f = 4*fi + fj the frequency of U = G g G^T; see wino_item_index for the
+// order inside a plane.  Backward-data multiplies by the filter rotated by 180 degrees with the channel roles swapped.
 __host__ __device__ inline long long wino_image_elems(int K, int N) { return 16ll * K * N; }
 
 // (G g G^T)[fi][fj], G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
@@ -22,15 +21,17 @@ __device__ inline float wino_u_of_g(const float (&g)[3][3], int f) {
 }
 
 // Work item j of an image = one (contraction channel k, produced channel no) pair, all 16 frequencies: element
-// ((j >> 9) * 16 + f) * 512 + (j & 511) for f = 0..15 (N = produced channels).
+// ((j >> 9) * 16 + f) * 512 + (j & 511) for f = 0..15 (N = produced channels).  Inside a (chunk, N block, f) plane of
+// 512 floats the order is the MFMA B-fragment order of the kernel: [half 2][lane 64][4], lane = 16 * kq + n holding
+// (k = 2 kq, 2 kq + 1) of channel 16 * (2 half) + n, then of channel 16 * (2 half + 1) + n.
 __device__ inline void wino_item_index(long long j, int N, int& k, int& no) {
   const int NB = N >> 6;
-  const int kp = (int)(j & 7), n = (int)((j >> 3) & 63);
+  const int w = (int)(j & 511);
+  const int e = w & 1, ntl = (w >> 1) & 1, l = (w >> 2) & 63, h = w >> 8;
   const long long rest = j >> 9;
   const int nb = (int)(rest % NB), c = (int)(rest / NB);
-  const int q = (kp >> 1) ^ (((n >> 3) & 1) << 1) ^ ((n >> 4) & 3);
-  k = c * 8 + q * 2 + (kp & 1);
-  no = nb * 64 + n;
+  k = c * 8 + 2 * (l >> 4) + e;
+  no = nb * 64 + (2 * h + ntl) * 16 + (l & 15);
 }
 __device__ inline void wino_store_item(float* __restrict__ img, long long j, const float (&g)[3][3]) {
   float* o = img + (j >> 9) * (16 * 512) + (j & 511);

@@ -111,7 +111,8 @@ int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, 
  * The fp32 3x3 / stride 1 / pad 1 layers with wide channel counts (the residual blocks, networks.py:603-624) and those
  * phase kernels run as Winograd F(2x2, 3x3) on the fp32 matrix pipe: their images are U = G g G^T (16 frequencies per
  * channel pair, laid out for the kernel's direct-to-LDS loads; _WINOGRAD_DGRAD: of the filter rotated by 180 degrees with
- * the channel roles swapped; _SUBPIXEL_WINOGRAD: of the four merged phase filters).  Same results as the direct form to
+ * the channel roles swapped; _SUBPIXEL_WINOGRAD: of the four merged phase filters; _WINOGRAD_S2: of the four 2x2 parity
+ * filters of a 4x4 / stride 2 layer, F(3x3, 2x2)).  Same results as the direct form to
  * fp32 rounding (the algorithm cuDNN uses for the reference's own fp32 3x3 convolutions).
  * Weights change only at optimizer.step() (scripts/trainer.py:252-268), so the caller may keep these images: query
  * the size (0 = the pass uses w as it is), fill a munit_prep_item on the host with munit_conv2d_prep_item, build
@@ -120,7 +121,8 @@ int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, 
  * wp == NULL those behave exactly like munit_conv2d_fwd / _dgrad (image rebuilt into the workspace per call). */
 enum { MUNIT_PASS_FWD = 0, MUNIT_PASS_DGRAD = 1, MUNIT_PASS_WGRAD = 2 };
 enum { MUNIT_PREP_NONE = 0, MUNIT_PREP_DGRAD = 1, MUNIT_PREP_SUBPIXEL = 2, MUNIT_PREP_CAST = 3,
-       MUNIT_PREP_WINOGRAD = 4, MUNIT_PREP_WINOGRAD_DGRAD = 5, MUNIT_PREP_SUBPIXEL_WINOGRAD = 6 };
+       MUNIT_PREP_WINOGRAD = 4, MUNIT_PREP_WINOGRAD_DGRAD = 5, MUNIT_PREP_SUBPIXEL_WINOGRAD = 6,
+       MUNIT_PREP_WINOGRAD_S2 = 7 };
 typedef struct {
   const float* w; /* [Cout][KH][KW][Cin] */
   float* wp;      /* image, munit_conv2d_prepared_weight_bytes() bytes (bf16 elements when bf16 != 0) */

@@ -875,7 +875,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
-  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) return 4 * wino_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2) return 4 * wino_image_elems(it.Cin, it.Cout);
   return cc * it.KH * it.KW;
 }
 
@@ -883,7 +883,8 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
 // item passed by value), grid-stride over the item's elements in x
 // loop trips of one image: its elements, or -- Winograd images -- its (k, n) channel pairs (16 elements each)
 __host__ __device__ inline long long prep_trips(const PrepItem& it) {
-  const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
+  const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ||
+                    it.kind == MUNIT_PREP_WINOGRAD_S2;
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -895,6 +896,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
       wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
+    else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
@@ -1195,6 +1197,20 @@ bool wino_geometry_ok(const munit_conv_desc* d) {
          d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH;
 }
 bool wino_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
+// MUNIT_WINO_S2_MIN_BLOCKS: developer override of the threshold (tests use 1 to push small shapes through the kernel)
+long long wino_s2_min_blocks() {
+  static const long long v = getenv("MUNIT_WINO_S2_MIN_BLOCKS") ? atoll(getenv("MUNIT_WINO_S2_MIN_BLOCKS")) : 192;
+  return v;
+}
+// 4x4 / stride 2 / pad 1 fp32 layers (encoder down-sampling, discriminators): F(3x3, 2x2) over the four input phases
+bool wino_s2_fwd_ok(const munit_conv_desc* d) {
+  return d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->KH == 4 &&
+         d->KW == 4 && d->stride == 2 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH && d->H >= 4 && d->W >= 4 &&
+         munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD_S2") &&
+         // one block per CU and no split over K: only where the tile list fills most of the chip (the small layers of the
+         // style encoder and the discriminators stay on the implicit-GEMM kernel and its split-K)
+         (long long)cdiv((long long)d->B * cdiv(d->H / 2, 3) * cdiv(d->W / 2, 3), 64) * (d->Cout / 64) >= wino_s2_min_blocks();
+}
 // the four 3x3 phase convs of a sub-pixel up-sampling layer (over the SOURCE image) through the Winograd kernel
 bool subpixel_wino_ok(const munit_conv_desc* d) {
   return subpixel_ok(d) && d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 &&
@@ -1209,6 +1225,7 @@ munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* w
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
   if (subpixel_ok(d)) it.kind = subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
   else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
+  else if (wino_s2_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD_S2;
   else if (it.bf16) it.kind = MUNIT_PREP_CAST;
   return it;
 }
@@ -1223,7 +1240,7 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
   if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return munit_small_fwd_workspace(d);
-  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d)) return img;
+  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d) || wino_s2_fwd_ok(d)) return img;
   if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
     const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
     return c.x4_bytes + c.w4_bytes;
@@ -1273,11 +1290,23 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
       wimg = it.wp;
     }
   }
+  if (it.kind == MUNIT_PREP_WINOGRAD_S2) {
+    WinoParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
+    q.y_sw = d->Cout; q.y_sh = (long long)Wo * d->Cout; q.y_sb = (long long)Ho * Wo * d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = 4 * d->Cin; q.N = d->Cout; q.xc = d->Cin; q.cpp = d->Cin / 8;
+    q.s2 = 1; q.Ho = Ho; q.Wo = Wo;
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
+    q.th = cdiv(Ho, 3); q.tw = cdiv(Wo, 3); q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cout / 64;
+    q.act = d->act; q.slope = d->slope;
+    return munit_wino_launch(q, st);
+  }
   if (it.kind == MUNIT_PREP_WINOGRAD) {
     WinoParams q{};
     q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
     q.y_sw = d->Cout; q.y_sh = (long long)d->W * d->Cout; q.y_sb = (long long)d->H * d->W * d->Cout;
-    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout; q.xc = d->Cin; q.cpp = d->Cin / 8;
     q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
     q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
     q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cout / 64;
@@ -1334,7 +1363,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
       wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
       wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
       wq.u_phase = wino_image_elems(d->Cin, d->Cout); wq.y_prow = q.y_phase_row; wq.y_pcol = q.y_phase_col; wq.phases = 4;
-      wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout;
+      wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout; wq.xc = d->Cin; wq.cpp = d->Cin / 8;
       wq.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
       wq.mode = 1;
       wq.th = d->H / 2; wq.tw = d->W / 2; wq.bth = cdiv(wq.th, 8); wq.btw = cdiv(wq.tw, 8); wq.NB = d->Cout / 64;
@@ -1539,7 +1568,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
     WinoParams q{};
     q.x = dy; q.u = wt; q.bias = nullptr; q.y = dx;
     q.y_sw = d->Cin; q.y_sh = (long long)d->W * d->Cin; q.y_sb = (long long)d->H * d->W * d->Cin;
-    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cout; q.N = d->Cin;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cout; q.N = d->Cin; q.xc = d->Cout; q.cpp = d->Cout / 8;
     q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cout * 4);
     q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 2 : 1;
     q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cin / 64;
@@ -1714,9 +1743,12 @@ extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_s
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
   const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
   const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
+  const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2;
+  MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
+                  "conv2d_prepare_weights: stride-2 Winograd image needs a 4x4 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
   MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
                   "conv2d_prepare_weights: sub-pixel Winograd image needs a 5x5 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
-  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || (item->kind == MUNIT_PREP_CAST && item->bf16),
+  MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || ws2 || (item->kind == MUNIT_PREP_CAST && item->bf16),
                   "conv2d_prepare_weights: bad kind %d", item->kind);
   MUNIT_CHECK_ARG(!wino || (item->KH == 3 && item->KW == 3 && !item->bf16 &&
                             (item->kind == MUNIT_PREP_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
@@ -1746,6 +1778,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
     if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36
+    if (wino_s2_fwd_ok(d)) return 4 * cc * d->B * cdiv(Ho, 3) * cdiv(Wo, 3) * 16;   // per 3x3 tile and input phase
     if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile
       return 2.0 * d->Cout * d->B * Ho * Wo * plan_cin4(1, 1, d->KH * d->KW).kpad;
     return cc * d->B * Ho * Wo * d->KH * d->KW;

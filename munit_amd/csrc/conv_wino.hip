@@ -49,7 +49,12 @@ __device__ inline float wino_act(float v, int act, float slope) {
 //    row 1 is dy row 0 under filter row 0, and inside the top tile (output rows 0, 1; patch rows -1 .. 2) filter row 0
 //    meets patch row 3 for output row 1 only -- so patch row 3 += patch row 1 there; mirrored at the bottom (patch row
 //    0 += patch row 2) and along the columns, the corners get the product of both.  Exact: the transform is linear.
-template <int MODE>
+// S2: the 4x4 / stride 2 / pad 1 layers.  Over the four input phases (row and column parity of the padded image) such a
+// layer is a sum of four 2x2 / stride 1 VALID convolutions, and F(3x3, 2x2) shares everything with F(2x2, 3x3) but the
+// small matrices: the same 4x4 patch, the same B^T, sixteen frequencies -- G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1] and
+// A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1] (3x3 outputs per tile).  The contraction runs phase-major over K = 4 Cin (the loader
+// re-derives its 16 patch offsets when the phase changes); 16 instead of 36 multiply-accumulates per tile again.
+template <int MODE, bool S2 = false>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   constexpr bool REFLECT = MODE == 0;
   __shared__ __attribute__((aligned(16))) float smem[WINO_SMEM];
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   }
   const int n_blk = blk % p.NB;
   int m_blk = blk / p.NB;
+  const int m_blk0 = m_blk;
   const int btx = m_blk % p.btw; m_blk /= p.btw;
   const int bty = m_blk % p.bth;
   const int b = m_blk / p.bth;
@@ -72,30 +78,59 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   // ---- loader (waves 0-3 only): thread = (tile tl, channel pair cp of the chunk); waves 4-7 only multiply ----
   const bool loader = wave < 4;
   const int tl = (tid & 255) >> 2, cp = tid & 3;
-  const int gy = min(bty * 8 + (tl >> 3), p.th - 1), gx = min(btx * 8 + (tl & 7), p.tw - 1);   // clamped: stores are predicated
+  // tile of this loader thread, clamped (stores are predicated).  3x3 layers: 8x8 tiles of image b; S2: 64 consecutive tiles
+  // of the batch-wide list (b, ty, tx) -- 3x3-pixel tiles rarely divide the extent, and whole 8x8 blocks would waste up to a
+  // quarter of the slots
+  int gy, gx, gb = b;
+  if constexpr (S2) {
+    const int t = min(m_blk0 * 64 + tl, p.B * p.th * p.tw - 1);
+    gx = t % p.tw; gy = (t / p.tw) % p.th; gb = t / (p.tw * p.th);
+  } else {
+    gy = min(bty * 8 + (tl >> 3), p.th - 1); gx = min(btx * 8 + (tl & 7), p.tw - 1);
+  }
   unsigned off[16];
-  {
+  // byte offsets of the thread's 4x4 patch (channel pair cp of the first chunk of a phase); padding that is not a reflection
+  // and everything past the image = an offset beyond the buffer, which the load returns as 0
+  auto make_off = [&](int phase) {
     int ro[4], co[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int ih = 2 * gy - 1 + i, iw = 2 * gx - 1 + i;
-      if (REFLECT) {
-        ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
-        iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+      int ih, iw;
+      if constexpr (S2) {   // row q of phase plane r is padded row 2q + r = image row 2q + r - 1
+        ih = 2 * (3 * gy + i) + (phase >> 1) - 1;
+        iw = 2 * (3 * gx + i) + (phase & 1) - 1;
+        if (REFLECT) {
+          ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
+          iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
+        }
+      } else {
+        ih = 2 * gy - 1 + i; iw = 2 * gx - 1 + i;
+        if (REFLECT) {
+          ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
+          iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+        }
       }
-      ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W * p.K : -1;
-      co[i] = (unsigned)iw < (unsigned)p.W ? iw * p.K + 2 * cp : -1;
+      ro[i] = (unsigned)ih < (unsigned)p.H ? (gb * p.H + ih) * p.W * p.xc : -1;
+      co[i] = (unsigned)iw < (unsigned)p.W ? iw * p.xc + 2 * cp : -1;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) off[i * 4 + j] = (ro[i] >= 0 && co[j] >= 0) ? (unsigned)(ro[i] + co[j]) * 4u : 0x80000000u;
-  }
+  };
+  make_off(0);
+  int off_phase = 0;
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   f32x2 d[16];
   auto load_raw = [&](int c) {
+    int cc = c;
+    if constexpr (S2) {
+      const int phase = c / p.cpp;
+      cc = c - phase * p.cpp;
+      if (phase != off_phase) { make_off(phase); off_phase = phase; }   // wave-uniform
+    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, off[q], c * (WK * 4), 0));
+    for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, off[q], cc * (WK * 4), 0));
   };
   const int vpos = tl * 8 + ((cp ^ (((tl >> 3) & 1) << 1) ^ ((tl >> 4) & 3)) << 1);
   const bool e_top = gy == 0, e_bot = gy == p.th - 1, e_left = gx == 0, e_right = gx == p.tw - 1;
@@ -183,25 +218,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   };
 
   // One barrier per chunk publishes V(c+1) and frees V(c-1)'s buffer; it is the only synchronisation left.
-  //   loader waves (0-3):     U(c) requested first, consumed after the transform of chunk c+1 (a register set of 16);
-  //   multiplier waves (4-7): U(c+1) requested while chunk c multiplies (two register sets, ping-pong), so they start on
-  //                           the V fragments the moment the barrier opens.
+  // Every wave requests U(c+1) while chunk c multiplies (two register sets, ping-pong): inside the step the 4 MB image of a
+  // layer is not L2-resident as it is in a back-to-back timing loop, and a request issued only at the start of its own chunk
+  // (tried for the loader waves, which are short of registers) made the step 1.4 % slower while the loop timing improved.
   const int nc = p.K / WK;
   if (loader) {
+    UFrag u0, u1;
     load_raw(0);
+    load_u(0, u0);
     transform_store(0);
     if (nc > 1) load_raw(1);
     __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-      const int cur = c & 1;
-      UFrag u;
-      load_u(c, u);
+    auto body = [&](int c, int cur, const UFrag& u, UFrag& un) {
       if (c + 1 < nc) {
+        load_u(c + 1, un);
         transform_store(cur ^ 1);
         if (c + 2 < nc) load_raw(c + 2);
       }
       compute(cur, u);
       __syncthreads();
+    };
+    for (int c = 0; c < nc; c += 2) {
+      body(c, 0, u0, u1);
+      if (c + 1 < nc) body(c + 1, 1, u1, u0);
     }
   } else {
     UFrag u0, u1;
@@ -241,20 +280,43 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
       float m[16];
 #pragma unroll
       for (int f = 0; f < 16; ++f) m[f] = smem[(f * 64 + t2) * MLD + co];
-      float s[8];   // A^T m: rows 0, 1
+      if constexpr (S2) {   // A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]: 3x3 pixels, the ragged last tile clipped
+        float s[12];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s[j] = (m[0 + j] + m[4 + j]) + m[8 + j];
-        s[4 + j] = (m[4 + j] - m[8 + j]) - m[12 + j];
-      }
-      const int ty = bty * 8 + (t2 >> 3), tx = btx * 8 + (t2 & 7);
-      if (ty < p.th && tx < p.tw) {
-        float* yp = p.y + (phase >> 1) * p.y_prow + (phase & 1) * p.y_pcol + b * p.y_sb + (long long)(2 * ty) * p.y_sh +
-                    (long long)(2 * tx) * p.y_sw + n;
-        yp[0] = wino_act(((s[0] + s[1]) + s[2]) + bv, p.act, slope);
-        yp[p.y_sw] = wino_act(((s[1] - s[2]) - s[3]) + bv, p.act, slope);
-        yp[p.y_sh] = wino_act(((s[4] + s[5]) + s[6]) + bv, p.act, slope);
-        yp[p.y_sh + p.y_sw] = wino_act(((s[5] - s[6]) - s[7]) + bv, p.act, slope);
+        for (int j = 0; j < 4; ++j) {
+          s[j] = (m[0 + j] + m[4 + j]) + m[8 + j];
+          s[4 + j] = m[4 + j] - m[8 + j];
+          s[8 + j] = (m[4 + j] + m[8 + j]) - m[12 + j];
+        }
+        const int t = m_blk0 * 64 + t2;
+        if (t < p.B * p.th * p.tw) {
+          const int tx = t % p.tw, ty = (t / p.tw) % p.th, tb = t / (p.tw * p.th);
+          float* yp = p.y + tb * p.y_sb + (long long)(3 * ty) * p.y_sh + (long long)(3 * tx) * p.y_sw + n;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float v[3] = {(s[i * 4 + 0] + s[i * 4 + 1]) + s[i * 4 + 2], s[i * 4 + 1] - s[i * 4 + 2],
+                                (s[i * 4 + 1] + s[i * 4 + 2]) - s[i * 4 + 3]};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (3 * ty + i < p.Ho && 3 * tx + j < p.Wo) yp[i * p.y_sh + j * p.y_sw] = wino_act(v[j] + bv, p.act, slope);
+          }
+        }
+      } else {
+        const int ty = bty * 8 + (t2 >> 3), tx = btx * 8 + (t2 & 7);
+        float s[8];   // A^T m: rows 0, 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[j] = (m[0 + j] + m[4 + j]) + m[8 + j];
+          s[4 + j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+        }
+        if (ty < p.th && tx < p.tw) {
+          float* yp = p.y + (phase >> 1) * p.y_prow + (phase & 1) * p.y_pcol + b * p.y_sb + (long long)(2 * ty) * p.y_sh +
+                      (long long)(2 * tx) * p.y_sw + n;
+          yp[0] = wino_act(((s[0] + s[1]) + s[2]) + bv, p.act, slope);
+          yp[p.y_sw] = wino_act(((s[1] - s[2]) - s[3]) + bv, p.act, slope);
+          yp[p.y_sh] = wino_act(((s[4] + s[5]) + s[6]) + bv, p.act, slope);
+          yp[p.y_sh + p.y_sw] = wino_act(((s[5] - s[6]) - s[7]) + bv, p.act, slope);
+        }
       }
     }
     if (half == 0) __syncthreads();
@@ -547,9 +609,15 @@ bool munit_wino_ok(int B, int H, int W, int K, int N) {
 }
 
 int munit_wino_launch(const WinoParams& p, hipStream_t st) {
-  const long long blocks = (long long)p.B * p.bth * p.btw * p.NB;
+  const long long blocks = p.s2 ? (long long)cdiv((long long)p.B * p.th * p.tw, 64) * p.NB : (long long)p.B * p.bth * p.btw * p.NB;
   MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
   const dim3 grid((unsigned)blocks, (unsigned)std::max(1, p.phases));
+  if (p.s2) {
+    if (p.mode == 0) hipLaunchKernelGGL((conv_wino_kernel<0, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(512), 0, st, p);
+    MUNIT_CHECK_LAUNCH("conv_wino_s2");
+    return MUNIT_OK;
+  }
   if (p.mode == 0) hipLaunchKernelGGL(conv_wino_kernel<0>, grid, dim3(512), 0, st, p);
   else if (p.mode == 1) hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL(conv_wino_kernel<2>, grid, dim3(512), 0, st, p);

@@ -52,6 +52,36 @@ __device__ inline void wino_weight_item(const float* __restrict__ w, float* __re
   wino_store_item(img, j, g);
 }
 
+// 4x4 / stride 2 layers (conv_wino.hip, S2): contraction index k = phase * Cin + ci with phase = 2 r + s the parity of the
+// filter tap (kh, kw) = (2a + r, 2b + s); the 2x2 filter of a phase is g[a][b] = w[no][2a + r][2b + s][ci], and
+// U = G g G^T with G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1].  w is [Cout][4][4][Cin]; items = 4 * Cin * Cout.
+__device__ inline void wino_s2_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
+  int k, no;
+  wino_item_index(j, Cout, k, no);
+  const int phase = k / Cin, ci = k - phase * Cin, r = phase >> 1, sft = phase & 1;
+  float g[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) g[a][b] = w[(((long long)no * 4 + 2 * a + r) * 4 + 2 * b + sft) * Cin + ci];
+  float t[4][2];   // G g
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b]);
+    t[3][b] = g[1][b];
+  }
+  float* o = img + (j >> 9) * (16 * 512) + (j & 511);
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi) {
+    o[(fi * 4 + 0) * 512] = t[fi][0];
+    o[(fi * 4 + 1) * 512] = 0.5f * (t[fi][0] + t[fi][1]);
+    o[(fi * 4 + 2) * 512] = 0.5f * (t[fi][0] - t[fi][1]);
+    o[(fi * 4 + 3) * 512] = t[fi][1];
+  }
+}
+
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv (conv_igemm.hip, prep_subpixel_elem): phase (a, b) of the output is a
 // 3x3 conv over the source with the 5 filter rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (columns
 // likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin]; items = 4 * Cin * Cout.
@@ -88,7 +118,9 @@ struct WinoParams {
   long long u_phase, y_prow, y_pcol;
   int phases;
   unsigned x_bytes;    // extent of x for the buffer loads
-  int B, H, W, K, N;   // output extent = input extent (3x3, stride 1, pad 1)
+  int B, H, W, K, N;   // K = contraction length (s2: 4 * xc), N = output channels; 3x3 layers: output extent = H x W
+  int xc, cpp;         // channels per pixel of x; chunks of 8 channels per input phase (= K / 8 unless s2)
+  int s2, Ho, Wo;      // 4x4 / stride 2 / pad 1 layer (F(3x3, 2x2) over four input phases): output extent Ho x Wo
   int mode;            // 0 reflect padding, 1 zero padding, 2 zero padding + border fold (backward-data of a reflect layer)
   int th, tw;          // 2x2 output tiles per image axis
   int bth, btw;        // 8x8-tile blocks per image axis

@@ -64,6 +64,9 @@ CONV_CASES = [
     (128, 256, 3, 1, 1, "reflect", 0, "none", 1, 32, 48),
     (64, 64, 3, 1, 1, "reflect", 0, "none", 1, 2, 2),       # one tile: the backward-weight chunk is 7/8 empty
     (64, 192, 3, 1, 1, "zero", 0, "none", 3, 6, 10),        # 45 tiles: ragged last chunk, zero padding, three N-blocks
+    # 4x4 / stride 2 layers as F(3x3, 2x2) over the four input phases: zero padding, ragged 3x3 tiles, a 26x26 output
+    (64, 64, 4, 2, 1, "zero", 0, "lrelu", 2, 10, 14),
+    (8, 128, 4, 2, 1, "reflect", 0, "none", 1, 52, 52),
 ]
 
 
@@ -95,6 +98,20 @@ def test_conv_fwd_bwd(case):
     assert nerr(xd.grad, xr.grad) <= BWD_TOL, ("dx", nerr(xd.grad, xr.grad))
     assert nerr(wd.grad, wr.grad) <= BWD_TOL, ("dw", nerr(wd.grad, wr.grad))
     assert nerr(bd.grad, br.grad) <= BWD_TOL, ("db", nerr(bd.grad, br.grad))
+
+
+def test_conv_stride2_winograd_on_small_shapes():
+    """The F(3x3, 2x2) kernel of the 4x4 / stride 2 layers only takes shapes that fill the chip (no split over K); the
+    library reads MUNIT_WINO_S2_MIN_BLOCKS once per process, so a child process with the threshold at 1 pushes the small
+    stride-2 cases of CONV_CASES (ragged 3x3 tiles, zero padding, one-block grids) through it."""
+    import os, subprocess, sys
+    env = dict(os.environ, MUNIT_WINO_S2_MIN_BLOCKS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_conv_fwd_bwd and k4s2", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
 def test_conv_wgrad_accumulates_into_buffer():

@@ -875,7 +875,8 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
-  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2) return 4 * wino_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD)
+    return 4 * wino_image_elems(it.Cin, it.Cout);
   return cc * it.KH * it.KW;
 }
 
@@ -884,7 +885,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
 // loop trips of one image: its elements, or -- Winograd images -- its (k, n) channel pairs (16 elements each)
 __host__ __device__ inline long long prep_trips(const PrepItem& it) {
   const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ||
-                    it.kind == MUNIT_PREP_WINOGRAD_S2;
+                    it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -897,6 +898,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
       wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
+    else if (it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD) wino_s2_dgrad_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
@@ -1211,6 +1213,17 @@ bool wino_s2_fwd_ok(const munit_conv_desc* d) {
          // style encoder and the discriminators stay on the implicit-GEMM kernel and its split-K)
          (long long)cdiv((long long)d->B * cdiv(d->H / 2, 3) * cdiv(d->W / 2, 3), 64) * (d->Cout / 64) >= wino_s2_min_blocks();
 }
+// backward-data of those layers: dy has extent H/2 x W/2 and Cout channels (the contraction), dx Cin channels
+bool wino_s2_dgrad_ok(const munit_conv_desc* d) {
+  if (!(d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->KH == 4 &&
+        d->KW == 4 && d->stride == 2 && d->pad == 1 && d->upsample == 0 && d->H >= 4 && d->W >= 4 && d->H % 2 == 0 && d->W % 2 == 0 &&
+        d->Cout % 8 == 0 && d->Cin % 64 == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD_S2") && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD")))
+    return false;
+  const int Hd = d->H / 2, Wd = d->W / 2;
+  if (d->pad_mode == MUNIT_PAD_REFLECT && (Hd % 3 == 0 || Wd % 3 == 0)) return false;   // fold pairs must share a 3x3 tile
+  if ((long long)d->B * d->H * d->W * std::max(d->Cin, d->Cout) >= (1ll << 29)) return false;
+  return (long long)cdiv((long long)d->B * cdiv(Hd + 1, 3) * cdiv(Wd + 1, 3), 64) * (d->Cin / 64) * 4 >= wino_s2_min_blocks();
+}
 // the four 3x3 phase convs of a sub-pixel up-sampling layer (over the SOURCE image) through the Winograd kernel
 bool subpixel_wino_ok(const munit_conv_desc* d) {
   return subpixel_ok(d) && d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 &&
@@ -1413,6 +1426,7 @@ struct DgradPlan {
   bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
   bool bf16s;   // dy (and the weight image) are bf16 in HBM: bf16-storage kernels (direct-to-LDS forms only)
   bool patch;   // folded with at most two padded positions per axis: the LDS-patch form
+  bool wino_s2; // 4x4 stride-2 pad-1 fp32 layer: four F(3x3, 2x2) parity phases over dy (conv_wino.hip, KIND 2)
   bool wino;    // 3x3 stride-1 pad-1 fp32 layer: Winograd F(2x2, 3x3) with the border fold in the input patch (conv_wino.hip)
   bool cin4;    // three output channels (the image head): dy re-laid with a zero 4th channel, direct-to-LDS 4-channel taps
   size_t wt_bytes, g_bytes, sk_bytes, c4_bytes;
@@ -1464,6 +1478,14 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   }
   pl->patch = pl->folded && d->upsample == 0 && max_fold_cands(d->H, 0, d->pad, reflect) <= 2 &&
               max_fold_cands(d->W, 0, d->pad, reflect) <= 2;
+  pl->wino_s2 = wino_s2_dgrad_ok(d);
+  if (pl->wino_s2) {
+    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = pl->wino = false;
+    pl->wt_bytes = align_up((size_t)4 * wino_image_elems(d->Cout, d->Cin) * 4, 256);
+    pl->g_bytes = 256;
+    pl->sk_bytes = pl->c4_bytes = pl->small_ws = 0;
+    return MUNIT_OK;
+  }
   pl->wino = wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cout, d->Cin);
   if (pl->wino) {
     pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = false;
@@ -1558,11 +1580,33 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
   float* g = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + pl.wt_bytes);
   const bool direct = pl.direct && add == nullptr;
   if (wt == nullptr) {   // no prepared image from the caller: re-lay the weights into the workspace
-    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin, pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD,
-                pl.ps, pl.bf16s ? 1 : 0};
+    PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin,
+                pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD, pl.ps, pl.bf16s ? 1 : 0};
     rc = launch_prep_one(it, st);
     if (rc) return rc;
     wt = it.wp;
+  }
+  if (pl.wino_s2) {
+    WinoParams q{};
+    const int Hd = d->H / 2, Wd = d->W / 2;
+    q.x = dy; q.u = wt; q.bias = nullptr; q.y = dx;
+    q.y_sw = d->Cin; q.y_sh = (long long)d->W * d->Cin; q.y_sb = (long long)d->H * d->W * d->Cin;
+    q.B = d->B; q.H = Hd; q.W = Wd; q.K = d->Cout; q.N = d->Cin; q.xc = d->Cout; q.cpp = d->Cout / 8;
+    q.s2 = 2; q.Ho = d->H; q.Wo = d->W;
+    q.x_bytes = (unsigned)((size_t)d->B * Hd * Wd * d->Cout * 4);
+    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
+    q.th = cdiv(Hd + 1, 3); q.tw = cdiv(Wd + 1, 3); q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cin / 64;
+    q.u_phase = wino_image_elems(d->Cout, d->Cin); q.phases = 4;
+    q.act = MUNIT_ACT_NONE; q.slope = 0.f;
+    rc = munit_wino_launch(q, st);
+    if (rc) return rc;
+    if (add != nullptr) {
+      long long n = (long long)d->B * d->H * d->W * d->Cin;
+      int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+      hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, dx, add, n);
+      MUNIT_CHECK_LAUNCH("add_inplace");
+    }
+    return MUNIT_OK;
   }
   if (pl.wino) {
     WinoParams q{};
@@ -1725,7 +1769,7 @@ extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const 
     DgradPlan pl;
     rc = plan_dgrad(d, &pl);
     if (rc) return rc;
-    it.kind = pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD;
+    it.kind = pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD;
     it.ps = pl.ps;
     it.bf16 = pl.bf16s ? 1 : 0;
   }
@@ -1743,9 +1787,11 @@ extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_s
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
   const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
   const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
-  const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2;
-  MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
-                  "conv2d_prepare_weights: stride-2 Winograd image needs a 4x4 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
+  const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2 || item->kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
+  MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 &&
+                           (item->kind == MUNIT_PREP_WINOGRAD_S2 ? item->Cin % 8 == 0 && item->Cout % 64 == 0
+                                                                 : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
+                  "conv2d_prepare_weights: stride-2 Winograd image needs a 4x4 fp32 filter, K %% 8 == 0, N %% 64 == 0");
   MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
                   "conv2d_prepare_weights: sub-pixel Winograd image needs a 5x5 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
   MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || ws2 || (item->kind == MUNIT_PREP_CAST && item->bf16),
@@ -1786,6 +1832,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   DgradPlan pl;
   if (plan_dgrad(d, &pl)) return 0.0;
   if (pl.wino) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
+  if (pl.wino_s2) return 4 * cc * d->B * cdiv(d->H / 2 + 1, 3) * cdiv(d->W / 2 + 1, 3) * 16;
   if (pl.boxsum) return cc * d->B * ((double)(d->H - 4) * (d->W - 4) + 4.0 * d->W + 4.0 * (d->H - 4)) * d->KH * d->KW;
   if (pl.folded) return cc * d->B * d->H * d->W * d->KH * d->KW;
   if (pl.direct) return cc * d->B * Ho * Wo * d->KH * d->KW;

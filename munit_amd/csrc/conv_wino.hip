@@ -54,9 +54,16 @@ __device__ inline float wino_act(float v, int act, float slope) {
 // small matrices: the same 4x4 patch, the same B^T, sixteen frequencies -- G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1] and
 // A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1] (3x3 outputs per tile).  The contraction runs phase-major over K = 4 Cin (the loader
 // re-derives its 16 patch offsets when the phase changes); 16 instead of 36 multiply-accumulates per tile again.
-template <int MODE, bool S2 = false>
+// KIND 2: backward-data of such a layer.  Per axis the padded gradient splits by the parity of its index q = 2u + par into
+// dxp[u] = sum_a dy[u - a] w[2a + par], a 2-tap correlation over dy: four launch phases (gridDim.y = row, column parity), each an
+// F(3x3, 2x2) convolution over the dense dy with the taps reversed and the channel roles swapped, written to every other row /
+// column of dx (image row q - 1).  The padded rows q = 0 and q = H + 1 fold (reflect padding) onto image rows 1 and H - 2,
+// which sit in the same 3x3 tile of the same phase (the host admits the layer only when H/2 is not a multiple of 3): the
+// epilogue adds them in registers before the store; with zero padding they are dropped.
+template <int MODE, int KIND = 0>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   constexpr bool REFLECT = MODE == 0;
+  constexpr bool S2 = KIND == 1, DG2 = KIND == 2, LIN = KIND != 0;
   __shared__ __attribute__((aligned(16))) float smem[WINO_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   // of the batch-wide list (b, ty, tx) -- 3x3-pixel tiles rarely divide the extent, and whole 8x8 blocks would waste up to a
   // quarter of the slots
   int gy, gx, gb = b;
-  if constexpr (S2) {
+  if constexpr (LIN) {
     const int t = min(m_blk0 * 64 + tl, p.B * p.th * p.tw - 1);
     gx = t % p.tw; gy = (t / p.tw) % p.th; gb = t / (p.tw * p.th);
   } else {
@@ -103,6 +110,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
           iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
         }
+      } else if constexpr (DG2) {   // dense dy, 3x3 tiles of the padded-gradient plane: rows 3 gy - 1 .. 3 gy + 2 (zeros outside)
+        ih = 3 * gy - 1 + i; iw = 3 * gx - 1 + i;
       } else {
         ih = 2 * gy - 1 + i; iw = 2 * gx - 1 + i;
         if (REFLECT) {
@@ -280,7 +289,61 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
       float m[16];
 #pragma unroll
       for (int f = 0; f < 16; ++f) m[f] = smem[(f * 64 + t2) * MLD + co];
-      if constexpr (S2) {   // A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]: 3x3 pixels, the ragged last tile clipped
+      if constexpr (DG2) {
+        float s[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[j] = (m[0 + j] + m[4 + j]) + m[8 + j];
+          s[4 + j] = m[4 + j] - m[8 + j];
+          s[8 + j] = (m[4 + j] + m[8 + j]) - m[12 + j];
+        }
+        const int t = m_blk0 * 64 + t2;
+        if (t < p.B * p.th * p.tw) {
+          const int tx = t % p.tw, ty = (t / p.tw) % p.th, tb = t / (p.tw * p.th);
+          const int ph = phase >> 1, pw = phase & 1;
+          float v[3][3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            v[i][0] = (s[i * 4 + 0] + s[i * 4 + 1]) + s[i * 4 + 2];
+            v[i][1] = s[i * 4 + 1] - s[i * 4 + 2];
+            v[i][2] = (s[i * 4 + 1] + s[i * 4 + 2]) - s[i * 4 + 3];
+          }
+          // plane index u = 3 ty + i  <->  padded row 2u + ph  <->  image row 2u + ph - 1.  Fold rows: u = 0 of parity 0 onto
+          // u = 1; u = H (the plane's last) of parity 1 onto u = H - 1; columns likewise.  p.H, p.W = extent of dy.
+          const int fr = ph == 0 ? 0 : p.H, fc = pw == 0 ? 0 : p.W;   // folding plane row / column
+          const int dr = ph == 0 ? 1 : -1, dc = pw == 0 ? 1 : -1;     // its target sits one step inside
+          if (REFLECT) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (3 * ty + i == fr) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                  if (i + dr >= 0 && i + dr < 3) v[i + dr][j] += v[i][j];
+                }
+              }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (3 * tx + j == fc) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                  if (j + dc >= 0 && j + dc < 3) v[i][j + dc] += v[i][j];
+                }
+              }
+          }
+          float* yb = p.y + tb * p.y_sb + n;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int u = 3 * ty + i, ir = 2 * u + ph - 1;
+            if (u == fr || ir < 0 || ir >= p.Ho) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int w = 3 * tx + j, ic = 2 * w + pw - 1;
+              if (w == fc || ic < 0 || ic >= p.Wo) continue;
+              yb[(long long)ir * p.y_sh + (long long)ic * p.y_sw] = v[i][j];
+            }
+          }
+        }
+      } else if constexpr (S2) {   // A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]: 3x3 pixels, the ragged last tile clipped
         float s[12];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -612,10 +675,16 @@ int munit_wino_launch(const WinoParams& p, hipStream_t st) {
   const long long blocks = p.s2 ? (long long)cdiv((long long)p.B * p.th * p.tw, 64) * p.NB : (long long)p.B * p.bth * p.btw * p.NB;
   MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
   const dim3 grid((unsigned)blocks, (unsigned)std::max(1, p.phases));
-  if (p.s2) {
-    if (p.mode == 0) hipLaunchKernelGGL((conv_wino_kernel<0, true>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(512), 0, st, p);
+  if (p.s2 == 1) {
+    if (p.mode == 0) hipLaunchKernelGGL((conv_wino_kernel<0, 1>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<1, 1>), grid, dim3(512), 0, st, p);
     MUNIT_CHECK_LAUNCH("conv_wino_s2");
+    return MUNIT_OK;
+  }
+  if (p.s2 == 2) {
+    if (p.mode == 0) hipLaunchKernelGGL((conv_wino_kernel<0, 2>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(512), 0, st, p);
+    MUNIT_CHECK_LAUNCH("conv_wino_s2_dgrad");
     return MUNIT_OK;
   }
   if (p.mode == 0) hipLaunchKernelGGL(conv_wino_kernel<0>, grid, dim3(512), 0, st, p);

@@ -82,6 +82,37 @@ __device__ inline void wino_s2_weight_item(const float* __restrict__ w, float* _
   }
 }
 
+// backward-data of a 4x4 / stride 2 layer: image [phase = 2 ph + pw][Cout / 8][Cin / 64][f][512]; the phase's 2x2 filter in
+// patch order is g[a][b] = w[k][2 (1 - a) + ph][2 (1 - b) + pw][no] (k = output channel of the layer = contraction index)
+__device__ inline void wino_s2_dgrad_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
+  const long long per = (long long)Cin * Cout;
+  const int phase = (int)(j / per), ph = phase >> 1, pw = phase & 1;
+  const long long jj = j - phase * per;
+  int k, no;
+  wino_item_index(jj, Cin, k, no);
+  float g[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) g[a][b] = w[(((long long)k * 4 + 2 * (1 - a) + ph) * 4 + 2 * (1 - b) + pw) * Cin + no];
+  float t[4][2];   // G g
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b]);
+    t[3][b] = g[1][b];
+  }
+  float* o = img + phase * wino_image_elems(Cout, Cin) + (jj >> 9) * (16 * 512) + (jj & 511);
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi) {
+    o[(fi * 4 + 0) * 512] = t[fi][0];
+    o[(fi * 4 + 1) * 512] = 0.5f * (t[fi][0] + t[fi][1]);
+    o[(fi * 4 + 2) * 512] = 0.5f * (t[fi][0] - t[fi][1]);
+    o[(fi * 4 + 3) * 512] = t[fi][1];
+  }
+}
+
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv (conv_igemm.hip, prep_subpixel_elem): phase (a, b) of the output is a
 // 3x3 conv over the source with the 5 filter rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (columns
 // likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin]; items = 4 * Cin * Cout.
@@ -120,7 +151,8 @@ struct WinoParams {
   unsigned x_bytes;    // extent of x for the buffer loads
   int B, H, W, K, N;   // K = contraction length (s2: 4 * xc), N = output channels; 3x3 layers: output extent = H x W
   int xc, cpp;         // channels per pixel of x; chunks of 8 channels per input phase (= K / 8 unless s2)
-  int s2, Ho, Wo;      // 4x4 / stride 2 / pad 1 layer (F(3x3, 2x2) over four input phases): output extent Ho x Wo
+  int s2, Ho, Wo;      // 1: 4x4 / stride 2 / pad 1 layer forward (F(3x3, 2x2) over four input phases), output extent Ho x Wo;
+                       // 2: its backward-data (x = dy of extent H x W, launch phases = parities, dx extent Ho x Wo)
   int mode;            // 0 reflect padding, 1 zero padding, 2 zero padding + border fold (backward-data of a reflect layer)
   int th, tw;          // 2x2 output tiles per image axis
   int bth, btw;        // 8x8-tile blocks per image axis

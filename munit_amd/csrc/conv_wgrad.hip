@@ -1095,11 +1095,20 @@ bool wino_wgrad_layer(const munit_conv_desc* d) {
   return d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->KH == 3 &&
          d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && munit_wino_wgrad_ok(d->B, d->H, d->W, d->Cin, d->Cout);
 }
+// 4x4 / stride 2 / pad 1 fp32 layers: F(3x3, 2x2) backward-weight, one launch phase per filter-tap parity
+bool wino_s2_wgrad_layer(const munit_conv_desc* d) {
+  return d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->KH == 4 &&
+         d->KW == 4 && d->stride == 2 && d->pad == 1 && d->upsample == 0 && d->H >= 4 && d->W >= 4 &&
+         munit_wino_wgrad_ok(d->B, d->H, d->W, d->Cin, d->Cout) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD_S2") &&
+         (long long)d->B * cdiv(d->H / 2, 3) * cdiv(d->W / 2, 3) >= (getenv("MUNIT_WINO_S2_MIN_BLOCKS") ? 1 : 512);
+}
+long long s2_tiles(const munit_conv_desc* d) { return (long long)d->B * cdiv(d->H / 2, 3) * cdiv(d->W / 2, 3); }
 }  // namespace
 
 extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0;
+  if (wino_s2_wgrad_layer(d)) return munit_wino_wgrad_workspace(s2_tiles(d), d->Cin, d->Cout, 4);
   if (wino_wgrad_layer(d)) return munit_wino_wgrad_workspace((long long)d->B * (d->H / 2) * (d->W / 2), d->Cin, d->Cout, 1);
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return munit_small_wgrad_workspace(d, Ho);
   if (subpixel_wgrad_ok(d)) {
@@ -1123,6 +1132,7 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   if (pass != MUNIT_PASS_WGRAD || munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
   const double cc = 2.0 * d->Cin * d->Cout;
   if (wino_wgrad_layer(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
+  if (wino_s2_wgrad_layer(d)) return 4 * cc * (double)s2_tiles(d) * 16;
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return cc * d->B * Ho * Wo * d->KH * d->KW;
   if (subpixel_wgrad_ok(d)) {  // 4 phase gradients over the interior source pixels + the 25-tap frame
     SubpixelPlan sp;
@@ -1145,6 +1155,17 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (wino_s2_wgrad_layer(d)) {
+    WinoWgradParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4); q.dy_bytes = (unsigned)((size_t)d->B * Ho * Wo * d->Cout * 4);
+    q.dy_sw = d->Cout; q.dy_sh = (long long)Wo * d->Cout; q.dy_sb = (long long)Ho * Wo * d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
+    q.reflect = d->pad_mode == MUNIT_PAD_REFLECT;
+    q.th = cdiv(Ho, 3); q.tw = cdiv(Wo, 3); q.phases = 4;
+    q.s2 = 1; q.Ho = Ho; q.Wo = Wo;
+    return munit_wino_wgrad_launch(q, dw, 0, db, beta, beta, ws, st);
+  }
   if (wino_wgrad_layer(d)) {
     WinoWgradParams q{};
     q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);

@@ -401,6 +401,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
 constexpr int WG_PLANE = 4 * 64 * 2;        // floats per frequency plane: [tile pair 4][channel 64][2]
 constexpr int WG_BUF = 16 * WG_PLANE;       // floats per operand buffer (32 KiB)
 
+// S2: the 4x4 / stride 2 layers, F(3x3, 2x2): launch phase = parity (r, s) of the filter tap; its 2x2 gradient contracts the
+// 3x3 tiles of dy (A dY A^T with A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1]) against the 4x4 patches of input phase (r, s).
+template <bool S2>
 __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * WG_BUF];   // E0 E1 V0 V1
   const int tid = threadIdx.x, lane = tid & 63;
@@ -417,9 +420,10 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
   const unsigned xlane = (unsigned)(cib * 64 + lane) * 4u, ylane = (unsigned)(cob * 64 + lane) * 4u;
-  const bool want_db = p.db_part != nullptr && cib == 0;
+  const bool want_db = p.db_part != nullptr && cib == 0 && (!S2 || phase == 0);
 
-  float d[16], g[4];
+  constexpr int NG = S2 ? 9 : 4;   // dy values per tile
+  float d[16], g[NG];
   float dbs = 0.f;
   // tile `wave` of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit)
   auto load_raw = [&](int c) {
@@ -429,10 +433,19 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
       int ro[4], co[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int ih = 2 * ty + p.xo + i, iw = 2 * tx + p.xo + i;
-        if (p.reflect) {
-          ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
-          iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+        int ih, iw;
+        if constexpr (S2) {   // row q of input phase r = image row 2q + r - 1; the padded rows -1 and H reflect (or read 0)
+          ih = 2 * (3 * ty + i) + (phase >> 1) - 1; iw = 2 * (3 * tx + i) + (phase & 1) - 1;
+          if (p.reflect) {
+            ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
+            iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
+          }
+        } else {
+          ih = 2 * ty + p.xo + i; iw = 2 * tx + p.xo + i;
+          if (p.reflect) {
+            ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
+            iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+          }
         }
         ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
         co[i] = (unsigned)iw < (unsigned)p.W ? iw : -1;
@@ -447,25 +460,58 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
             d[i * 4 + j] = 0.f;
         }
       const int sw = (int)p.dy_sw * 4, sh = (int)p.dy_sh * 4;
-      const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
-      g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
-      g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
-      g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
-      g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
+      if constexpr (S2) {
+        const int y0 = (int)(p.dy_off + b * p.dy_sb) * 4 + 3 * ty * sh + 3 * tx * sw;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            if (3 * ty + i < p.Ho && 3 * tx + j < p.Wo)
+              g[i * 3 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + i * sh + j * sw, 0));
+            else
+              g[i * 3 + j] = 0.f;
+          }
+      } else {
+        const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
+        g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
+        g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
+        g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
+        g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) d[q] = 0.f;
-      g[0] = g[1] = g[2] = g[3] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) g[q] = 0.f;
     }
   };
   // plane position of (tile pair kq = wave >> 1, channel lane, element wave & 1); odd pairs swap the two 16-channel
   // halves of every 32 so that the half-wave fragment reads below (pairs {0,1} or {2,3}) cover all 64 banks
   const int wpos = ((wave >> 1) * 64 + (lane ^ (((wave >> 1) & 1) << 4))) * 2 + (wave & 1);
   auto transform_store = [&](int buf) {
-    if (want_db) dbs += (g[0] + g[1]) + (g[2] + g[3]);
     float* E = smem + buf * WG_BUF + wpos;
     float* V = smem + (2 + buf) * WG_BUF + wpos;
-    {  // E = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+    if constexpr (S2) {
+      if (want_db) dbs += ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + g[8];
+      // E = A dY A^T, A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1]
+      float r[4][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        r[0][j] = g[j];
+        r[1][j] = (g[j] + g[6 + j]) + g[3 + j];
+        r[2][j] = (g[j] + g[6 + j]) - g[3 + j];
+        r[3][j] = -g[6 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        E[(i * 4 + 0) * WG_PLANE] = r[i][0];
+        E[(i * 4 + 1) * WG_PLANE] = (r[i][0] + r[i][2]) + r[i][1];
+        E[(i * 4 + 2) * WG_PLANE] = (r[i][0] + r[i][2]) - r[i][1];
+        E[(i * 4 + 3) * WG_PLANE] = -r[i][2];
+      }
+    } else {
+      if (want_db) dbs += (g[0] + g[1]) + (g[2] + g[3]);
+      // E = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
       const float r[4][2] = {{g[0], g[1]}, {g[0] + g[2], g[1] + g[3]}, {g[0] - g[2], g[1] - g[3]}, {-g[2], -g[3]}};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -578,12 +624,12 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
 // up the bias partials.
 __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ db_part, float* __restrict__ dw,
                                          long long dw_phase, float* __restrict__ db, int Cout, int Cin, int ksplit, float beta,
-                                         float beta_b, int pair_blocks) {
-  if ((int)blockIdx.x >= pair_blocks) {   // bias: all phases and splits, phase-0 blocks only
+                                         float beta_b, int pair_blocks, int s2) {
+  if ((int)blockIdx.x >= pair_blocks) {   // bias: all phases and splits (s2: the partials of phase 0 only), phase-0 blocks only
     const int co = (blockIdx.x - pair_blocks) * blockDim.x + threadIdx.x;
     if (co < Cout && blockIdx.y == 0) {
       float s = 0.f;
-      for (int k = 0; k < ksplit * (int)gridDim.y; ++k) s += db_part[k * Cout + co];
+      for (int k = 0; k < ksplit * (s2 ? 1 : (int)gridDim.y); ++k) s += db_part[k * Cout + co];
       db[co] = beta_b == 0.f ? s : beta_b * db[co] + s;
     }
     return;
@@ -601,6 +647,25 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const f
     const float* sp = slab + (long long)k * 16 * plane + idx;
 #pragma unroll
     for (int f = 0; f < 16; ++f) S[f] += sp[f * plane];
+  }
+  if (s2) {   // 2x2 gradient of filter-tap parity (r, s) = launch phase: G^T = [1 .5 .5 0; 0 .5 -.5 1]; dw is [Cout][4][4][Cin]
+    const int r = blockIdx.y >> 1, sf = blockIdx.y & 1;
+    float t[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = S[j] + 0.5f * (S[4 + j] + S[8 + j]);
+      t[1][j] = 0.5f * (S[4 + j] - S[8 + j]) + S[12 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float v[2] = {t[a][0] + 0.5f * (t[a][1] + t[a][2]), 0.5f * (t[a][1] - t[a][2]) + t[a][3]};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float* o = dw - blockIdx.y * dw_phase + (((long long)co * 4 + 2 * a + r) * 4 + 2 * b + sf) * Cin + ci;
+        *o = beta == 0.f ? v[b] : beta * *o + v[b];
+      }
+    }
+    return;
   }
   // G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
   float t[3][4];
@@ -655,12 +720,14 @@ int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, fl
   float* db_part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
                                             align_up((size_t)p.ksplit * p.phases * 16 * p.Cin * p.Cout * sizeof(float), 256));
   p.db_part = db != nullptr ? db_part : nullptr;
-  hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(p.CB * p.NB * p.ksplit), (unsigned)p.phases), dim3(512), 0, st, p);
+  const dim3 grid((unsigned)(p.CB * p.NB * p.ksplit), (unsigned)p.phases);
+  if (p.s2) hipLaunchKernelGGL(conv_wino_wgrad_kernel<true>, grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv_wino_wgrad_kernel<false>, grid, dim3(512), 0, st, p);
   MUNIT_CHECK_LAUNCH("conv_wino_wgrad");
   const int pair_blocks = cdiv((long long)p.Cout * p.Cin, 256);
   const int bias_blocks = db != nullptr ? cdiv(p.Cout, 256) : 0;
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + bias_blocks), (unsigned)p.phases), dim3(256), 0, st, p.slab,
-                     db_part, dw, dw_phase, db, p.Cout, p.Cin, p.ksplit, beta, beta_b, pair_blocks);
+                     db_part, dw, dw_phase, db, p.Cout, p.Cin, p.ksplit, beta, beta_b, pair_blocks, p.s2);
   MUNIT_CHECK_LAUNCH("wino_wgrad_reduce");
   return MUNIT_OK;
 }

@@ -181,6 +181,7 @@ struct WinoWgradParams {
   int cps;             // chunks (of 8 tiles) per split
   int CB, NB, ksplit;  // Cin / 64, Cout / 64, splits of the tile range
   int phases;
+  int s2, Ho, Wo;      // 4x4 / stride 2 layer: dy extent Ho x Wo, 3x3 tiles, launch phase = filter-tap parity (x phase)
 };
 bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout);
 // splits of the tile range, and the workspace (slabs + bias partials) for `phases` launch phases over `tiles` tiles

@@ -875,6 +875,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return cc * it.KH * it.KW + 4 * wino_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD)
     return 4 * wino_image_elems(it.Cin, it.Cout);
   return cc * it.KH * it.KW;
@@ -886,6 +887,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
 __host__ __device__ inline long long prep_trips(const PrepItem& it) {
   const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ||
                     it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return (long long)it.Cout * it.Cin * (it.KH * it.KW + 4);
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -899,6 +901,11 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD) wino_s2_dgrad_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
+    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) {
+      const long long nd = (long long)it.Cout * it.Cin * it.KH * it.KW;   // the transposed weights first (frame launch) ...
+      if (i < nd) prep_dgrad_elem(it, i);
+      else wino_subpixel_dgrad_weight_item(it.w, it.wp + nd, it.Cout, it.Cin, i - nd);   // ... then the Winograd image
+    }
     else if (it.kind == MUNIT_PREP_CAST) prep_cast_elem(it, i);
     else prep_dgrad_elem(it, i);
   }
@@ -1426,6 +1433,7 @@ struct DgradPlan {
   bool boxsum;  // up-sampling 5x5 conv: interior through the 2x2 box sum of dy, 2-pixel frame through the folded gather
   bool bf16s;   // dy (and the weight image) are bf16 in HBM: bf16-storage kernels (direct-to-LDS forms only)
   bool patch;   // folded with at most two padded positions per axis: the LDS-patch form
+  bool upwino;  // boxsum layer whose interior runs as one Winograd launch over the four dy phases (conv_wino.hip, KIND 3)
   bool wino_s2; // 4x4 stride-2 pad-1 fp32 layer: four F(3x3, 2x2) parity phases over dy (conv_wino.hip, KIND 2)
   bool wino;    // 3x3 stride-1 pad-1 fp32 layer: Winograd F(2x2, 3x3) with the border fold in the input patch (conv_wino.hip)
   bool cin4;    // three output channels (the image head): dy re-laid with a zero 4th channel, direct-to-LDS 4-channel taps
@@ -1480,7 +1488,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
               max_fold_cands(d->W, 0, d->pad, reflect) <= 2;
   pl->wino_s2 = wino_s2_dgrad_ok(d);
   if (pl->wino_s2) {
-    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = pl->wino = false;
+    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = pl->wino = pl->upwino = false;
     pl->wt_bytes = align_up((size_t)4 * wino_image_elems(d->Cout, d->Cin) * 4, 256);
     pl->g_bytes = 256;
     pl->sk_bytes = pl->c4_bytes = pl->small_ws = 0;
@@ -1488,7 +1496,7 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   }
   pl->wino = wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cout, d->Cin);
   if (pl->wino) {
-    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = false;
+    pl->direct = pl->folded = pl->small = pl->patch = pl->boxsum = pl->bf16s = pl->cin4 = pl->upwino = pl->wino_s2 = false;
     pl->wt_bytes = align_up((size_t)wino_image_elems(d->Cout, d->Cin) * 4, 256);
     pl->g_bytes = 256;
     pl->sk_bytes = pl->c4_bytes = pl->small_ws = 0;
@@ -1501,8 +1509,12 @@ int plan_dgrad(const munit_conv_desc* d, DgradPlan* pl) {
   if (pl->bf16s && !pl->patch) pl->folded = false;
   pl->boxsum = pl->folded && !pl->bf16s && d->in_dtype == MUNIT_DTYPE_F32 && d->upsample == 1 && d->KH == 5 && d->pad == 2 &&
                reflect && d->Cout % 32 == 0 && d->Cin % 4 == 0 && d->H >= 8 && d->W >= 8 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_BOXSUM");
+  pl->upwino = pl->boxsum && d->compute == MUNIT_COMPUTE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->H % 2 == 0 && d->W % 2 == 0 &&
+               d->Cout % 8 == 0 && d->Cin % 64 == 0 && (long long)d->B * 4 * d->H * d->W * d->Cout < (1ll << 29) &&
+               !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD");
   const size_t esz = d->in_dtype == MUNIT_DTYPE_BF16 ? 2 : 4;   // element size of dx and g
   pl->wt_bytes = align_up((size_t)d->Cout * d->KH * d->KW * d->Cin * (pl->bf16s ? 2 : 4), 256);
+  if (pl->upwino) pl->wt_bytes = align_up(((size_t)d->Cout * 25 * d->Cin + (size_t)4 * wino_image_elems(d->Cout, d->Cin)) * 4, 256);
   pl->g_bytes = align_up((size_t)d->B * pl->Hq * pl->Wq * d->Cin * esz, 256);
   if (pl->folded) pl->g_bytes = 256;  // no padded-domain buffer (an `add` operand falls back, see below)
   if (pl->boxsum) pl->g_bytes = align_up((size_t)d->B * pl->Ho * pl->Wo * d->Cout * sizeof(float), 256);  // S
@@ -1581,7 +1593,8 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
   const bool direct = pl.direct && add == nullptr;
   if (wt == nullptr) {   // no prepared image from the caller: re-lay the weights into the workspace
     PrepItem it{w, reinterpret_cast<float*>(ws), d->Cout, d->KH, d->KW, d->Cin,
-                pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD, pl.ps, pl.bf16s ? 1 : 0};
+                pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD
+                : pl.upwino ? MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD, pl.ps, pl.bf16s ? 1 : 0};
     rc = launch_prep_one(it, st);
     if (rc) return rc;
     wt = it.wp;
@@ -1668,7 +1681,25 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
     p.patch = pl.patch;
     p.bf16s = pl.bf16s; p.out_bf16 = dx_bf16;
     MUNIT_CHECK_ARG(!dx_bf16 || pl.bf16s || pl.patch, "conv2d_dgrad: unsupported dtype combination");
-    if (pl.boxsum) {
+    if (pl.boxsum && pl.upwino) {
+      // interior source pixels 2..H-3 x 2..W-3 as ONE Winograd launch: the four output phases of dy are 3x3-correlated with the
+      // rotated merged filters and summed (K = 4 Cout); no box sum, no padding
+      WinoParams wq{};
+      wq.x = dy; wq.u = wt + (size_t)d->Cout * 25 * d->Cin; wq.bias = nullptr;
+      wq.y = dx + ((long long)2 * d->W + 2) * d->Cin;
+      wq.y_sw = d->Cin; wq.y_sh = (long long)d->W * d->Cin; wq.y_sb = (long long)d->H * d->W * d->Cin;
+      wq.B = d->B; wq.H = pl.Ho; wq.W = pl.Wo; wq.K = 4 * d->Cout; wq.N = d->Cin; wq.xc = d->Cout; wq.cpp = d->Cout / 8;
+      wq.s2 = 3;
+      wq.x_bytes = (unsigned)((size_t)d->B * pl.Ho * pl.Wo * d->Cout * 4);
+      wq.mode = 1;
+      wq.th = (d->H - 4) / 2; wq.tw = (d->W - 4) / 2; wq.bth = cdiv(wq.th, 8); wq.btw = cdiv(wq.tw, 8); wq.NB = d->Cin / 64;
+      wq.act = MUNIT_ACT_NONE; wq.slope = 0.f;
+      rc = munit_wino_launch(wq, st);
+      if (rc) return rc;
+      p.frame = 1;
+      p.M = d->B * (4 * d->W + 4 * (d->H - 4));
+      rc = launch_igemm<2>(p, 1, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
+    } else if (pl.boxsum) {
       // interior source pixels 2..H-3 x 2..W-3: dx[i][j] = sum_taps wt[t][r] . S[2i-2+t][2j-2+r] -- one gather per element
       {
         const long long total = (long long)d->B * pl.Ho * pl.Wo * (d->Cout / 4);
@@ -1769,7 +1800,8 @@ extern "C" int munit_conv2d_prep_item(const munit_conv_desc* d, int pass, const 
     DgradPlan pl;
     rc = plan_dgrad(d, &pl);
     if (rc) return rc;
-    it.kind = pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD;
+    it.kind = pl.wino_s2 ? MUNIT_PREP_WINOGRAD_S2_DGRAD : pl.wino ? MUNIT_PREP_WINOGRAD_DGRAD
+              : pl.upwino ? MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD : MUNIT_PREP_DGRAD;
     it.ps = pl.ps;
     it.bf16 = pl.bf16s ? 1 : 0;
   }
@@ -1786,13 +1818,15 @@ extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, i
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
   const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
-  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD;
+  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD;
   const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2 || item->kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 &&
                            (item->kind == MUNIT_PREP_WINOGRAD_S2 ? item->Cin % 8 == 0 && item->Cout % 64 == 0
                                                                  : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
                   "conv2d_prepare_weights: stride-2 Winograd image needs a 4x4 fp32 filter, K %% 8 == 0, N %% 64 == 0");
-  MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 && item->Cin % 8 == 0 && item->Cout % 64 == 0),
+  MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 &&
+                           (item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
+                                                                       : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
                   "conv2d_prepare_weights: sub-pixel Winograd image needs a 5x5 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
   MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || ws2 || (item->kind == MUNIT_PREP_CAST && item->bf16),
                   "conv2d_prepare_weights: bad kind %d", item->kind);
@@ -1833,6 +1867,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (plan_dgrad(d, &pl)) return 0.0;
   if (pl.wino) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;
   if (pl.wino_s2) return 4 * cc * d->B * cdiv(d->H / 2 + 1, 3) * cdiv(d->W / 2 + 1, 3) * 16;
+  if (pl.boxsum && pl.upwino) return cc * d->B * ((double)((d->H - 4) / 2) * ((d->W - 4) / 2) * 4 * 16 + (4.0 * d->W + 4.0 * (d->H - 4)) * 25);
   if (pl.boxsum) return cc * d->B * ((double)(d->H - 4) * (d->W - 4) + 4.0 * d->W + 4.0 * (d->H - 4)) * d->KH * d->KW;
   if (pl.folded) return cc * d->B * d->H * d->W * d->KH * d->KW;
   if (pl.direct) return cc * d->B * Ho * Wo * d->KH * d->KW;

@@ -63,7 +63,10 @@ __device__ inline float wino_act(float v, int act, float slope) {
 template <int MODE, int KIND = 0>
 __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   constexpr bool REFLECT = MODE == 0;
-  constexpr bool S2 = KIND == 1, DG2 = KIND == 2, LIN = KIND != 0;
+  // KIND 3: backward-data of a sub-pixel up-sampling layer over its interior source pixels: the sum over the four output phases
+  // of 3x3 correlations of dy's phase planes (rows 2u + a) with the rotated merged filters -- F(2x2, 3x3) tiles, K = 4 Cout
+  // phase-major like KIND 1, no padding anywhere (the 2-pixel frame is the generic kernel's)
+  constexpr bool S2 = KIND == 1, DG2 = KIND == 2, UPD = KIND == 3, LIN = KIND == 1 || KIND == 2, PHK = KIND == 1 || KIND == 3;
   __shared__ __attribute__((aligned(16))) float smem[WINO_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
         }
       } else if constexpr (DG2) {   // dense dy, 3x3 tiles of the padded-gradient plane: rows 3 gy - 1 .. 3 gy + 2 (zeros outside)
         ih = 3 * gy - 1 + i; iw = 3 * gx - 1 + i;
+      } else if constexpr (UPD) {   // source pixel 2 gy + 2 + (0, 1): plane rows one before .. two after, image row 2u + a
+        ih = 2 * (2 * gy + 1 + i) + (phase >> 1); iw = 2 * (2 * gx + 1 + i) + (phase & 1);
       } else {
         ih = 2 * gy - 1 + i; iw = 2 * gx - 1 + i;
         if (REFLECT) {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   f32x2 d[16];
   auto load_raw = [&](int c) {
     int cc = c;
-    if constexpr (S2) {
+    if constexpr (PHK) {
       const int phase = c / p.cpp;
       cc = c - phase * p.cpp;
       if (phase != off_phase) { make_off(phase); off_phase = phase; }   // wave-uniform
@@ -739,13 +744,19 @@ bool munit_wino_ok(int B, int H, int W, int K, int N) {
 }
 
 int munit_wino_launch(const WinoParams& p, hipStream_t st) {
-  const long long blocks = p.s2 ? (long long)cdiv((long long)p.B * p.th * p.tw, 64) * p.NB : (long long)p.B * p.bth * p.btw * p.NB;
+  const bool lin = p.s2 == 1 || p.s2 == 2;
+  const long long blocks = lin ? (long long)cdiv((long long)p.B * p.th * p.tw, 64) * p.NB : (long long)p.B * p.bth * p.btw * p.NB;
   MUNIT_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_wino: bad grid");
   const dim3 grid((unsigned)blocks, (unsigned)std::max(1, p.phases));
   if (p.s2 == 1) {
     if (p.mode == 0) hipLaunchKernelGGL((conv_wino_kernel<0, 1>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_wino_kernel<1, 1>), grid, dim3(512), 0, st, p);
     MUNIT_CHECK_LAUNCH("conv_wino_s2");
+    return MUNIT_OK;
+  }
+  if (p.s2 == 3) {
+    hipLaunchKernelGGL((conv_wino_kernel<1, 3>), grid, dim3(512), 0, st, p);
+    MUNIT_CHECK_LAUNCH("conv_wino_up_dgrad");
     return MUNIT_OK;
   }
   if (p.s2 == 2) {

@@ -113,6 +113,31 @@ __device__ inline void wino_s2_dgrad_weight_item(const float* __restrict__ w, fl
   }
 }
 
+// backward-data of a sub-pixel up-sampling layer (interior source pixels): contraction index k = phase * Cout + co with
+// phase = 2a + b the output parity; filter of the phase in patch order = the merged 3x3 filter rotated by 180 degrees,
+// g[r][s] = wm_ab[co][2 - r][2 - s][ci]  (wm as in wino_subpixel_weight_item).  One image: [K = 4 Cout][N = Cin].
+__device__ inline void wino_subpixel_dgrad_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
+  int k, no;
+  wino_item_index(j, Cin, k, no);
+  const int ph = k / Cout, co = k - ph * Cout, a = ph >> 1, b = ph & 1;
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) {
+      const int dh = 2 - r, dw = 2 - sft;
+      const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
+      const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
+      const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
+      const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
+      float sum = 0.f;
+      for (int kh = h0; kh < h0 + hn; ++kh)
+        for (int kw = w0; kw < w0 + wn; ++kw) sum += w[(((long long)co * 5 + kh) * 5 + kw) * Cin + no];
+      g[r][sft] = sum;
+    }
+  wino_store_item(img, j, g);
+}
+
 // Sub-pixel form of nearest-x2-upsample + 5x5 conv (conv_igemm.hip, prep_subpixel_elem): phase (a, b) of the output is a
 // 3x3 conv over the source with the 5 filter rows merged as  a=0: {0,1} {2,3} {4}   a=1: {0} {1,2} {3,4}  (columns
 // likewise).  Image = [phase 4][the U image of that merged 3x3 filter]; w is [Cout][5][5][Cin]; items = 4 * Cin * Cout.

@@ -67,6 +67,9 @@ CONV_CASES = [
     # 4x4 / stride 2 layers as F(3x3, 2x2) over the four input phases: zero padding, ragged 3x3 tiles, a 26x26 output
     (64, 64, 4, 2, 1, "zero", 0, "lrelu", 2, 10, 14),
     (8, 128, 4, 2, 1, "reflect", 0, "none", 1, 52, 52),
+    # sub-pixel layers at the extents of the 64x64 step tests: several 8x8-tile blocks per axis in the backward-data
+    (256, 128, 5, 1, 2, "reflect", 1, "none", 2, 16, 16),
+    (128, 64, 5, 1, 2, "reflect", 1, "none", 1, 32, 32),
 ]
 
 

@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (16x the fp32 matrix rate)
 KERNEL_NAMES = {
-    "conv_wino_kernel<fwd>": "conv_wino_kernel<0> (Winograd F(2x2,3x3) forward of the 3x3 stride-1 layers on v_mfma_f32_16x16x4_f32)",
+    "conv_wino_kernel<fwd>": "conv_wino_kernel<0, 0> (Winograd F(2x2,3x3) forward of the 3x3 stride-1 layers on v_mfma_f32_16x16x4_f32)",
     "conv_igemm_kernel<128,true,fwd>": "conv_igemm_kernel<128,true,fwd> (forward implicit-GEMM conv, Cout>64, Cin%32==0)",
 }
 GFLOP_PER_PAIR_256 = 2789.6   # algorithmic conv+linear FLOPs of dis_update+gen_update
@@ -94,7 +94,7 @@ def pmc_traffic_bytes():
             PMC_SUMMARY, fp[0] if fp else "unknown", lib_fingerprint())
     try:
         for line in lines:
-            if line.startswith("conv_wino_kernel<0>") and "blocks=   512" in line:
+            if line.startswith("conv_wino_kernel<0, 0>") and "blocks=   512" in line:
                 f = line.split()
                 fetch = float(f[f.index("fetch") + 1])
                 write = float(f[f.index("write") + 1])

@@ -205,11 +205,12 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const T* __restrict__ 
       }
       for (int p = p0 + pl; p < p1; p += L.PL) {
         const long long o = base + (long long)p * C + qq * 4;
-        const f32x4 xh = (ld4(x + o) - mean) * rstd;
+        const f32x4 xv = ld4(x + o);
+        const f32x4 xh = (xv - mean) * rstd;
         f32x4 g = ld4(dy + o);
-        if (relu) {
+        if (relu) {   // the branch the FORWARD took: the same x * scale + shift, bit for bit (in_finalize / in_apply)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -290,11 +291,12 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ 
     const f32x4 bb = *reinterpret_cast<const f32x4*>(s_b + q * 4);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a1 + q * 4);
     const f32x4 a2 = *reinterpret_cast<const f32x4*>(s_a2 + q * 4);
-    const f32x4 xh = (ld4(x + base + i * 4) - mean) * rstd;
+    const f32x4 xv = ld4(x + base + i * 4);
+    const f32x4 xh = (xv - mean) * rstd;
     f32x4 g = ld4(dy + base + i * 4);
-    if (relu) {
+    if (relu) {   // the forward's own x * scale + shift (see in_bwd_stats_kernel)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xh[e] * w[e] + bb[e]) > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
     }
     const f32x4 r = rstd * w * (g - a1 - xh * a2);
     st4(dx + base + i * 4, r);
@@ -428,11 +430,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const T* __restrict__ 
       const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + qq * 4);
       for (int p = p0 + pl; p < p1; p += L.PL) {
         const long long o = base + (long long)p * C + qq * 4;
-        const f32x4 xn = (ld4(x + o) - mean) * inv;
+        const f32x4 xv = ld4(x + o);
+        const f32x4 xn = (xv - mean) * inv;
         f32x4 g = ld4(dy + o);
-        if (relu) {
+        if (relu) {   // the branch the forward took: x * (inv * gamma) + (beta - mean * inv * gamma), bit for bit (ln_apply)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e])) > 0.f ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -498,11 +501,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const T* __restrict__ 
     const int q = (int)(i % CQ);
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
-    const f32x4 xn = (ld4(x + base + i * 4) - mean) * inv;
+    const f32x4 xv = ld4(x + base + i * 4);
+    const f32x4 xn = (xv - mean) * inv;
     f32x4 g = ld4(dy + base + i * 4);
-    if (relu) {
+    if (relu) {   // the forward's own expression (see ln_bwd_stats_kernel)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xn[e] * gm[e] + bt[e]) > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e])) > 0.f ? g[e] : 0.f;
     }
     const f32x4 r = (g * gm - c1) * inv - xn * c2;
     st4(dx + base + i * 4, r);

@@ -4,6 +4,7 @@ normalised errors.  The oracle is the CHECKER here, never the thing measured or 
 import math
 
 import numpy as np
+import os
 import torch
 
 from oracle import munit_oracle as O
@@ -126,10 +127,15 @@ def trainer_named_params(trainer):
 
 
 def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", oracle_dtype=torch.float64,
-                    step_size=2, check=True, optimizer="adam", precision=None, guided=1, recon_mask=1, pin_kinks=True):
+                    step_size=2, check=True, optimizer="adam", precision=None, guided=1, recon_mask=1, pin_kinks=True,
+                    ref32=False):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
-    losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end)."""
+    losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end).
+    ref32=True (diagnostic): every iteration also evaluates the generator gradients with the ORACLE ITSELF in fp32 (torch CPU,
+    direct convolutions) on the same weights, inputs and pinned kinks, and reports per tensor how far that fp32 evaluation of the
+    reference is from fp64 (rep["ref32"]: list per iteration of (name, hip_max, hip_l2, ref32_max, ref32_l2)) -- the yardstick
+    for what any fp32 implementation can reach at that network state."""
     from munit_amd import ops
     from munit_amd.trainer import MUNIT_Trainer
 
@@ -213,7 +219,25 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         km = hip(lambda: tr.gen_update(dx_a, dx_b, hp, dm_a if recon_mask else None, dm_b if recon_mask else None),
                  200 + it)
         sa, sb = styles(200 + it)
+        g32 = None
+        if ref32 and oracle_dtype == torch.float64:
+            f32 = lambda st: {k: v.detach().float().clone() for k, v in st.items()}
+            orc32 = O.OracleTrainer(dict(hp), f32(orc.gen), f32(orc.dis_a), f32(orc.dis_b))
+            km32 = O.KinkMasks(list(km.masks), None if km.l1_signs is None else list(km.l1_signs)) if km is not None else None
+            g32 = oracle(lambda: orc32.gen_update(ox[0].float(), ox[1].float(), ox[2].float(), ox[3].float(), sa.float(), sb.float(),
+                                                  apply=False), km32)
         g_ref = oracle(lambda: orc.gen_update(ox[0], ox[1], ox[2], ox[3], sa, sb), km)
+        if g32 is not None:
+            rows = []
+            for (n, p), g, h in zip(gnames, g_ref, g32):
+                if g is None or float(g.abs().max()) < 1e-7:
+                    continue
+                rows.append((n, nerr(p._munit_grad, g), l2err(p._munit_grad, g), nerr(h, g), l2err(h, g)))
+                if os.environ.get("MUNIT_PARITY_DUMP") and n.endswith(os.environ["MUNIT_PARITY_DUMP"]):
+                    mine = p._munit_grad.detach().double().cpu().reshape(-1); refv = g.reshape(-1).double()
+                    top = (mine - refv).abs().topk(6).indices.tolist()
+                    print("DUMP", n, [(i, float(mine[i]), float(refv[i])) for i in top], flush=True)
+            rep.setdefault("ref32", []).append(rows)
         for (n, p), g in zip(gnames, g_ref):
             if g is None:
                 continue

@@ -41,26 +41,22 @@ class GradCheck:
     the kernels, and it used to be absorbed by a 5e-2 / 1e-1 per-tensor bound.  Now the HIP forward records the sign
     pattern behind every ReLU / LeakyReLU (ops.MASK_SINK) and the fp64 oracle takes the same branches
     (oracle.KINK_MASKS), so both sides differentiate the same piecewise-linear function and the comparison is tight:
-        pinned:    median relative L2 over the tensors <= 2e-5 (what a systematic error would break: measured 1.3e-6 .. 2e-6,
-                   1.1e-5 in the worst iteration); every tensor <= 1e-2 normalised max AND <= 5e-3 relative L2 (SURVEY.md
-                   8c's bound; it notes 2.2e-3 between the reference's own fp32 and fp64 runs) EXCEPT at most 3 % of the
-                   tensors of an iteration, which are listed by name in the report and stay <= 5e-2 / 1e-2.  Measured on
-                   MI355X with the Winograd layers (tools/parity_detail.py, 3 iterations at 64x64): most iterations have
-                   every tensor <= 4e-6; about one in three shows the tensors of ONE translation path (enc1_content, mlp2,
-                   dec2, the style encoder) at 5e-4 .. 7e-3 and a single tensor (the AdaIN-parameter layer mlp2.model.2) at
-                   1.07e-2 max / 8e-4 L2: a few of its elements belong to channels whose instance norm divides by
-                   sqrt(var + 1e-5) with var ~ 0 on the 16x16 test feature maps, which amplifies the forward rounding noise
-                   (1e-6 with the Winograd layers; 1e-7 with the direct kernels, MUNIT_DEBUG_NO_WINOGRAD=1, which never
-                   showed it) by up to 316 -- any fp32 evaluation of the reference moves by that much there.  One iteration
-                   at 128x128: worst 1.5e-4 max / 2.8e-5 L2.
+        pinned:    EVERY tensor <= 5e-5 normalised max AND <= 5e-5 relative L2, median L2 <= 1e-5 -- 200x below SURVEY.md 8c's
+                   1e-2.  Measured on MI355X with all Winograd layers (tools/parity_report.py): 3 iterations at 64x64 worst
+                   3.9e-6 max / 3.2e-6 L2, median 1.5e-6; gen_state 0: 4.3e-6 / 4.1e-6; 128x128: 3.1e-6 / 2.6e-6 -- below
+                   the deviation of the ORACLE ITSELF evaluated in fp32 on the CPU (5e-6 .. 7e-6 max, median 3.4e-6 .. 4.5e-6:
+                   tools/parity_ref32.py), i.e. the HIP step is as close to fp64 as an fp32 evaluation of the reference can be.
+                   (Until the norm kernels' backward took its ReLU branch from the forward's own expression, one iteration
+                   in three showed 5e-4 .. 1e-2 on one translation path: the re-derived pre-activation differed by rounding
+                   for near-degenerate AdaIN channels.  tools/parity_ref32.py is the tool that separated that from
+                   conditioning: the oracle in fp32 stayed at 7e-6 on the same state.)
         unpinned:  (diagnostic mode, pin_kinks=False) every tensor <= 5e-2 L2 / 1e-1 max, median <= 2e-3, and at
                    most 10 % of the tensors looser than 1e-2 max -- listed by name in the report."""
 
     def __init__(self, pinned=True):
         self.pinned = pinned
         if pinned:
-            # soft = SURVEY's per-tensor bound, may be exceeded by a listed few (ill-conditioned normalisations); hard = never
-            self.L2_MEDIAN, self.L2_SOFT, self.MAX_SOFT, self.L2_HARD, self.MAX_HARD, self.FRAC = 2e-5, 5e-3, 1e-2, 1e-2, 5e-2, 0.03
+            self.L2_MEDIAN, self.L2_SOFT, self.MAX_SOFT, self.L2_HARD, self.MAX_HARD, self.FRAC = 1e-5, 5e-5, 5e-5, 5e-5, 5e-5, 0.0
         else:
             self.L2_MEDIAN, self.L2_SOFT, self.MAX_SOFT, self.L2_HARD, self.MAX_HARD, self.FRAC = 2e-3, 5e-3, 1e-2, 5e-2, 1e-1, 0.10
         self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0
@@ -79,7 +75,7 @@ class GradCheck:
         self.median = sorted(self.l2s)[len(self.l2s) // 2] if self.l2s else 0.0
         if check:
             assert self.median <= self.L2_MEDIAN, ("median grad l2", self.median, self.loose)
-            assert len(self.loose) <= max(1, int(len(self.l2s) * self.FRAC)), ("too many tensors over SURVEY's bound", self.loose)
+            assert len(self.loose) <= int(len(self.l2s) * self.FRAC), ("tensors over the bound", self.loose)
 
 
 def oracle_states(hp, dtype):
@@ -280,6 +276,6 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         if check:
             assert rep["moment_l2"] <= 2 * gc.L2_SOFT, rep["moment_l2"]
             assert rep["weight_abs"] <= 4.0 * hp["lr"], rep["weight_abs"]
-            assert rep["weight_l2"] <= 2e-4, rep["weight_l2"]
+            assert rep["weight_l2"] <= 2e-4, rep["weight_l2"]     # measured <= 3e-5
     rep["weight_nerr"] = rep["weight_abs"]
     return rep

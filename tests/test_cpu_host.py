@@ -274,3 +274,81 @@ def test_compute_mode_plumbing_without_gpu():
     item = _lib.PrepItem()
     assert lib.munit_conv2d_prep_item(ctypes.byref(dup), 0, None, None, ctypes.byref(item)) == 0 and item.kind == 6
     assert lib.munit_conv2d_prepared_weight_bytes(ctypes.byref(dup), 0) == 4 * 16 * 128 * 64 * 4
+
+
+def test_winograd_algebra_of_the_kernels():
+    """The identities conv_wino.hip is built on, in fp64 numpy: F(2x2,3x3) and F(3x3,2x2) forward, their backward-weight form
+    dg = G^T [(A dY A^T) . (B^T d B)] G, the reflect fold of the 3x3 backward-data done inside the input patch, and the
+    parity split of the 4x4 / stride 2 layer (forward over four input phases; backward-data as four 2-tap phase planes whose
+    padded rows fold onto their neighbours)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
+    G3 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], float)
+    AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
+    G2 = np.array([[1, 0], [.5, .5], [.5, -.5], [0, 1]], float)
+    AT3 = np.array([[1, 1, 1, 0], [0, 1, -1, 0], [0, 1, 1, -1]], float)
+
+    def corr(d, g, m):   # VALID correlation, m x m outputs
+        r = g.shape[0]
+        return np.array([[(d[i:i + r, j:j + r] * g).sum() for j in range(m)] for i in range(m)])
+
+    d = rng.standard_normal((4, 4))
+    for G, AT, r, m in ((G3, AT2, 3, 2), (G2, AT3, 2, 3)):
+        g = rng.standard_normal((r, r))
+        y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
+        assert np.abs(y - corr(d, g, m)).max() < 1e-13
+        dy = rng.standard_normal((m, m))
+        dg = G.T @ ((AT.T @ dy @ AT) * (BT @ d @ BT.T)) @ G
+        ref = np.array([[(dy * d[a:a + m, b:b + m]).sum() for b in range(r)] for a in range(r)])
+        assert np.abs(dg - ref).max() < 1e-13
+
+    # 1-D reflect-pad-1 3-tap layer, H = 8: dx = P^T C^T dy.  Kernel form: zero-padded correlation of dy with the flipped
+    # filter, 2-output tiles over patches dy[2t-1 .. 2t+2]; top tile: patch row 3 += patch row 1, bottom tile: row 0 += row 2.
+    H, w = 8, rng.standard_normal(3)
+    x = rng.standard_normal(H)
+    dyv = rng.standard_normal(H)
+    xp = np.concatenate([[x[1]], x, [x[H - 2]]])
+    dxp = np.zeros(H + 2)
+    for o in range(H):
+        dxp[o:o + 3] += dyv[o] * w
+    dx_ref = dxp[1:H + 1].copy(); dx_ref[1] += dxp[0]; dx_ref[H - 2] += dxp[H + 1]
+    dyz = np.concatenate([[0.0], dyv, [0.0, 0.0]])
+    dx = np.zeros(H)
+    for t in range(H // 2):
+        p = dyz[2 * t:2 * t + 4].copy()                      # dy rows 2t-1 .. 2t+2
+        if t == 0: p[3] += p[1]
+        if t == H // 2 - 1: p[0] += p[2]
+        for i in range(2):
+            dx[2 * t + i] = sum(p[i + s] * w[2 - s] for s in range(3))
+    assert np.abs(dx - dx_ref).max() < 1e-13
+    assert abs(float((xp[0:3] * w).sum()) - float(sum(xp[k] * w[k] for k in range(3)))) < 1e-13   # (orientation of w)
+
+    # 1-D 4-tap / stride 2 / reflect-pad-1 layer, H = 8 -> 4 outputs: forward = sum over the input parities r of 2-tap
+    # correlations over phase plane X_r[q] = xp[2q + r]; backward-data = parity planes dxp[2u + par] = sum_a dy[u-a] w[2a+par],
+    # image row = padded row - 1, padded rows 0 and H+1 folding onto rows 1 and H-2
+    w4 = rng.standard_normal(4)
+    y = np.array([(xp[2 * o:2 * o + 4] * w4).sum() for o in range(H // 2)])
+    yp = np.zeros(H // 2)
+    for r in range(2):
+        Xr = xp[r::2]                                        # H/2 + 1 rows
+        yp += np.array([Xr[o] * w4[r] + Xr[o + 1] * w4[2 + r] for o in range(H // 2)])
+    assert np.abs(y - yp).max() < 1e-13
+    dyo = rng.standard_normal(H // 2)
+    dxp = np.zeros(H + 2)
+    for o in range(H // 2):
+        dxp[2 * o:2 * o + 4] += dyo[o] * w4
+    dx_ref = dxp[1:H + 1].copy(); dx_ref[1] += dxp[0]; dx_ref[H - 2] += dxp[H + 1]
+    dx = np.zeros(H)
+    Hd = H // 2
+    for par in range(2):
+        plane = np.array([sum((dyo[u - a] if 0 <= u - a < Hd else 0.0) * w4[2 * a + par] for a in range(2)) for u in range(Hd + 1)])
+        if par == 0:
+            plane[1] += plane[0]                             # padded row 0 -> image row 1 (same plane, u = 1)
+        else:
+            plane[Hd - 1] += plane[Hd]                       # padded row H+1 -> image row H-2 (same plane, u = Hd-1)
+        for u in range(Hd + 1):
+            i = 2 * u + par - 1
+            if 0 <= i < H and not (par == 0 and u == 0) and not (par == 1 and u == Hd):
+                dx[i] = plane[u]
+    assert np.abs(dx - dx_ref).max() < 1e-13

@@ -13,13 +13,15 @@
 //   * K runs in chunks of 8 channels.  Waves 0-3 are the loaders: per chunk a thread (tile, channel pair) reads its 4x4
 //     patch straight from global memory (buffer_load_dwordx2; neighbouring tiles overlap and the 4x re-read is served by
 //     the vector L1; zero padding = an out-of-range offset), transforms it in registers (packed adds) and writes 16
-//     pairs V[f][tile][k, k+1] to LDS.  Waves 4-7 start the chunk's transformed weights U[f][n][k] (32 KiB, contiguous in
-//     the prepared image) global -> LDS directly (global_load_lds_dwordx4) and multiply at once, so the matrix pipe of
-//     every SIMD is fed by its multiply-only wave while its loader wave transforms.  Measured on the trunk layer
-//     (tools/time_conv.py, back-to-back launches): all eight waves loading one channel each, four before and four after
-//     their MFMAs: 203 us; without that stagger 213; this split: 195.  Timing-only ablations of the symmetric form:
-//     without the patch loads 172, without the U loads 182, without loads and transform 167 us.
-//   * V and U are double buffered (2 x 2 x 32 KiB): one barrier per chunk;
+//     pairs V[f][tile][k, k+1] to LDS.  Waves 4-7 only multiply, so the matrix pipe of every SIMD is fed by its
+//     multiply-only wave while its loader wave transforms.  Measured on the trunk layer (tools/time_conv.py, back-to-back
+//     launches): all eight waves loading one channel each, four before and four after their MFMAs: 203 us; without that
+//     stagger 213; this split: 195; with U in registers (next item) 188.
+//   * The transformed weights U[f][n][k] never touch LDS: the two frequency planes of a wave are private to it, so it reads
+//     them from the prepared image (fragment order, L2) straight into registers, four global_load_dwordx4 per chunk,
+//     requested one chunk ahead.  (They used to travel global -> LDS with global_load_lds_dwordx4: issuing those cost 11 %
+//     of the launch in a timing-only ablation, and interleaving them with the MFMAs made it worse.)
+//   * V is double buffered (2 x 32 KiB): one barrier per chunk is the only synchronisation;
 //   * epilogue: the 16 frequency planes meet in LDS (two halves of 32 channels), one thread per (tile, channel) folds
 //     them into the 2x2 pixels, adds bias, applies the activation and stores 128-byte row segments.
 #include "wino.h"

@@ -376,6 +376,9 @@ def main():
                 # spends 16 multiply-accumulates where the algorithmic count (the contract's numerator) has 36, so
                 # `frac` can exceed 1 while the pipe itself runs at `executed_frac` of its peak
                 "executed_achieved": round(ach_x, 2), "executed_frac": round(ach_x / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": ("frac is priced on algorithmic FLOPs as the contract asks; the kernel is Winograd F(2x2,3x3), which issues "
+                         "16 of every 36 algorithmic multiply-accumulates, so frac > 1 is expected -- executed_frac prices the "
+                         "same launches on the FLOPs actually issued on the fp32 matrix pipe") if ach_x < ach else "",
                 "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                 "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),
                 "executed_gflop_per_launch_avg": round(tot_fx / len(sel) / 1e9, 3),

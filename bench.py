@@ -229,7 +229,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous on the CPU, no GPU work")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (opt-in; not the headline path)")
     ap.add_argument("--no-modes", action="store_true", help="skip the supplementary timing of the opt-in f32x3 mode")
     ap.add_argument("--precision", choices=["f32", "bf16", "bf16s", "f32x3"], default="f32",
                     help="f32 = the reference's arithmetic (the headline metric, BASELINE.json configs[1]); "
@@ -273,13 +272,6 @@ def main():
         trainer.update_learning_rate()
         trainer.dis_update(x_a, x_b, hp)
         trainer.gen_update(x_a, x_b, hp, m_a, m_b)
-
-    if args.graph:     # opt-in: the same step replayed from a hipGraph (munit_amd/graph.py); single process only
-        from munit_amd.graph import GraphedStep
-        graphed = GraphedStep(trainer, hp, x_a, x_b, m_a, m_b)
-
-        def step():    # noqa: F811
-            graphed(x_a, x_b, m_a, m_b)
 
     def fence():
         torch.cuda.synchronize()
@@ -328,9 +320,7 @@ def main():
                    "ms_per_step_min": round(per_step_ms[0], 3), "ms_per_step_max": round(per_step_ms[-1], 3)},
     }
 
-    if args.graph:
-        out["config"]["launch"] = "hipGraph replay (munit_amd/graph.py)"
-    if not args.no_roofline and args.precision == "f32" and not args.graph:
+    if not args.no_roofline and args.precision == "f32":
         # Every rank runs these extra steps (they contain the gradient all-reduces, so the collectives must stay
         # matched across ranks); rank 0 reports.
         step_flop = GFLOP_PER_PAIR_256 * 1e9 * (args.size / 256.0) ** 2 * args.batch
@@ -404,7 +394,7 @@ def main():
                            "kernel": "whole step (algorithmic conv+linear FLOPs / step time)",
                            "step_frac_vs_f32_mfma_peak": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                            "step_algorithmic_tflop": round(step_flop / 1e12, 3)}
-    if rank == 0 and world == 1 and args.precision == "f32" and not args.no_modes and not args.graph:
+    if rank == 0 and world == 1 and args.precision == "f32" and not args.no_modes:
         # supplementary, NOT the metric: the same step in the opt-in f32x3 mode (fp32 operands split exactly into three
         # bf16 planes, six product terms, fp32 accumulate; passes the fp32 parity tests at unchanged tolerances)
         del trainer

@@ -58,8 +58,6 @@ const char* munit_last_error(void);
  * for all work enqueued so far on `signaler`; both streams belong to the current device.  Used to fork backward-weight
  * onto a side stream without creating torch Event / Stream objects per layer. */
 int munit_stream_wait_stream(munit_stream_t waiter, munit_stream_t signaler);
-/* a and b each wait for what the other has enqueued so far (the cross-over points of the trainer's two branch streams). */
-int munit_stream_cross_wait(munit_stream_t a, munit_stream_t b);
 
 /* ------------------------------------------------------------------------------------
  * Convolution.  Replaces nn.ReflectionPad2d/ZeroPad2d + nn.Conv2d (+ bias + activation)
@@ -256,16 +254,6 @@ int munit_weighted_sum(const float* const* terms, const float* w, int n, float* 
  * ------------------------------------------------------------------------------------ */
 int munit_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
                     double beta2, double eps, double weight_decay, int step, munit_stream_t stream);
-
-/* The same update for a launch that is captured into a hipGraph and replayed (munit_amd/graph.py): the two scalars that
- * change from step to step -- lr / (1 - beta1^t) and sqrt(1 - beta2^t) -- are read from dyn[0], dyn[1] in DEVICE memory,
- * which the host refreshes before every replay (munit_store_floats: the values travel as kernel arguments, so a host
- * running ahead of the device cannot overwrite a pending update) with the values munit_adam_dynamic_scalars computes
- * (the same double -> float conversions as munit_adam_step, so the replayed step is bit-identical to the eager one). */
-void munit_adam_dynamic_scalars(double lr, double beta1, double beta2, int step, float* out2 /* host, 2 floats */);
-int munit_store_floats(float* dst, const float* vals_host, int n /* <= 8 */, munit_stream_t stream);
-int munit_adam_step_graph(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2,
-                          double eps, double weight_decay, const float* dyn, munit_stream_t stream);
 
 /* ExtraAdam (scripts/extraadam.py:14-168; selected by `optimizer: extra...`, scripts/trainer.py:41-45,
  * stepped by the *_opt_step methods, trainer.py:252-268: extrapolation on even iterations, step on odd).

@@ -47,7 +47,6 @@ SIGNATURES = {
     "munit_version": (c_int, []),
     "munit_last_error": (c_char_p, []),
     "munit_stream_wait_stream": (c_int, [_P, _P]),
-    "munit_stream_cross_wait": (c_int, [_P, _P]),
     "munit_conv2d_out_hw": (c_int, [_DESC, POINTER(c_int), POINTER(c_int)]),
     "munit_conv2d_fwd_workspace_bytes": (c_size_t, [_DESC]),
     "munit_conv2d_fwd": (c_int, [_DESC, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -96,9 +95,6 @@ SIGNATURES = {
     "munit_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _P, _P]),
     "munit_adam_step": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int,
                                 _P]),
-    "munit_adam_dynamic_scalars": (None, [c_double, c_double, c_double, c_int, POINTER(c_float)]),
-    "munit_store_floats": (c_int, [_P, POINTER(c_float), c_int, _P]),
-    "munit_adam_step_graph": (c_int, [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, _P, _P]),
     "munit_extraadam_step": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double,
                                      c_double, c_int, c_int, _P]),
     "munit_scale": (c_int, [_P, _P, c_size_t, c_float, c_int, _P]),

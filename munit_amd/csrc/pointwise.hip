@@ -193,13 +193,7 @@ __global__ void weighted_sum_kernel(WsumArgs a, float* out) {
 // torch.optim.Adam single-tensor update order (L2 weight decay folded into the gradient).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
-                            float wd, float bc2_sqrt, float omb1, float omb2, const float* __restrict__ dyn) {
-  // dyn (munit_adam_step_graph): the two step-dependent scalars live in device memory so that a captured launch can be
-  // replayed with the next step's learning rate and bias corrections
-  if (dyn != nullptr) {
-    step_size = dyn[0];
-    bc2_sqrt = dyn[1];
-  }
+                            float wd, float bc2_sqrt, float omb1, float omb2) {
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -401,46 +395,7 @@ extern "C" int munit_adam_step(float* p, const float* g, float* m, float* v, siz
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long long)n, 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
                      (long long)n, step_size, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc2_sqrt,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), (const float*)nullptr);
-  MUNIT_CHECK_LAUNCH("adam");
-  return MUNIT_OK;
-}
-
-extern "C" void munit_adam_dynamic_scalars(double lr, double beta1, double beta2, int step, float* out2) {
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2 = 1.0 - pow(beta2, (double)step);
-  out2[0] = (float)(lr / bc1);
-  out2[1] = (float)sqrt(bc2);
-}
-
-namespace {
-struct Small8 { float v[8]; };
-__global__ void store_floats_kernel(float* dst, Small8 vals, int n) {
-  if (threadIdx.x < (unsigned)n) dst[threadIdx.x] = vals.v[threadIdx.x];
-}
-}  // namespace
-
-// dst[i] = vals[i] (i < n <= 8; vals on the HOST).  The values travel as kernel arguments, i.e. they are read when the
-// call is made, not when the stream gets to it: a host that runs ahead of the device cannot overwrite them (a pinned
-// staging buffer reused every step raced with its own pending copy).
-extern "C" int munit_store_floats(float* dst, const float* vals, int n, munit_stream_t stream) {
-  MUNIT_CHECK_ARG(dst && vals && n > 0 && n <= 8, "store_floats: bad args");
-  Small8 s{};
-  for (int i = 0; i < n; ++i) s.v[i] = vals[i];
-  hipLaunchKernelGGL(store_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, s, n);
-  MUNIT_CHECK_LAUNCH("store_floats");
-  return MUNIT_OK;
-}
-
-extern "C" int munit_adam_step_graph(float* p, const float* g, float* m, float* v, size_t n, double beta1, double beta2,
-                                     double eps, double weight_decay, const float* dyn, munit_stream_t stream) {
-  MUNIT_CHECK_ARG(p && g && m && v && dyn && n > 0, "adam_step_graph: bad args");
-  MUNIT_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
-                      ((uintptr_t)v % 16 == 0),
-                  "adam_step_graph: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long long)n, 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v,
-                     (long long)n, 0.f, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, 1.f,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), dyn);
+                     (float)(1.0 - beta1), (float)(1.0 - beta2));
   MUNIT_CHECK_LAUNCH("adam");
   return MUNIT_OK;
 }

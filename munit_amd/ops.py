@@ -236,7 +236,11 @@ def _prepared(owner, w, pl, which):
         return None
     key = pl.prep_sig[which]
     ent = reg.get(key)
-    ver = owner._version
+    # in-place edits of the parameter bump its version; writes through the optimizer's flat buffer (flat_p.copy_,
+    # dist.broadcast(flat_p)) bump the buffer's.  Writes that bump neither (p.data.copy_, raw kernels) must be followed by
+    # FusedAdam.invalidate_prepared().
+    opt = getattr(owner, "_munit_opt", None)
+    ver = (owner._version, opt.flat_p._version if opt is not None and opt.flat_p is not None else 0)
     if ent is not None and ent[1] == ver:
         return ent[0]
     lib = _lib.load()
@@ -252,10 +256,8 @@ def _prepared(owner, w, pl, which):
     # other streams may use the image right away (the a / b branches share the style encoder): rare path, so simply
     # finish it before returning instead of carrying an event per parameter
     torch.cuda.current_stream().synchronize()
-    if fresh:
-        opt = getattr(owner, "_munit_opt", None)
-        if opt is not None:
-            opt.register_prepared(ent[2])
+    if fresh and opt is not None:
+        opt.register_prepared(ent[2])
     return ent[0]
 
 
@@ -377,17 +379,11 @@ def _side_stream(device):
 
 
 def stream_wait(waiter, signaler):
-    """`waiter` (torch.cuda.Stream) waits for everything enqueued so far on `signaler`, through the library's cached /
-    capture-safe events (munit_stream_wait_stream) instead of a torch Event object per edge."""
+    """`waiter` (torch.cuda.Stream) waits for everything enqueued so far on `signaler`, through the library's cached
+    event (munit_stream_wait_stream) instead of a torch Event object per edge."""
     with torch.cuda.device(waiter.device):
         _lib.check(_lib.load().munit_stream_wait_stream(c_void_p(waiter.cuda_stream), c_void_p(signaler.cuda_stream)),
                    "stream_wait_stream")
-
-
-def stream_cross_wait(a, b):
-    """Streams a and b each wait for the other's work so far."""
-    with torch.cuda.device(a.device):
-        _lib.check(_lib.load().munit_stream_cross_wait(c_void_p(a.cuda_stream), c_void_p(b.cuda_stream)), "stream_cross_wait")
 
 
 def join_side_streams():
@@ -767,25 +763,6 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     with _on(p):
         _lib.check(lib.munit_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
                                        float(eps), float(weight_decay), int(step), _stream()), "adam_step")
-
-
-def adam_step_graph(p, g, m, v, beta1, beta2, eps, weight_decay, dyn):
-    """Adam with the step-dependent scalars in the device buffer `dyn` (2 floats): for launches captured into a hipGraph."""
-    lib = _lib.load()
-    _same_device(p, g, m, v, dyn)
-    with _on(p):
-        _lib.check(lib.munit_adam_step_graph(_p(p), _p(g), _p(m), _p(v), p.numel(), float(beta1), float(beta2),
-                                             float(eps), float(weight_decay), _p(dyn), _stream()), "adam_step_graph")
-
-
-def adam_dynamic_scalars(lr, beta1, beta2, step, dyn):
-    """Compute the step's (lr / (1 - beta1^t), sqrt(1 - beta2^t)) and store them into the device buffer `dyn`, ordered on
-    the current stream; the values are captured when this call is made."""
-    lib = _lib.load()
-    out = (c_float * 2)()
-    lib.munit_adam_dynamic_scalars(float(lr), float(beta1), float(beta2), int(step), out)
-    with _on(dyn):
-        _lib.check(lib.munit_store_floats(_p(dyn), out, 2, _stream()), "store_floats")
 
 
 def extraadam_step(p, g, m, v, p_saved, lr, beta1, beta2, eps, weight_decay, step, mode):

@@ -44,9 +44,6 @@ class FusedAdam(Optimizer):
         # prepared weight images (ops._prepared): items registered on first use, refreshed in one launch per step
         self._prep_items = []
         self._prep_table = None
-        # hipGraph mode (munit_amd/graph.py): the step-dependent scalars of the update live in a device buffer that the
-        # replaying host refreshes; step() then neither counts steps nor bakes lr into its launch
-        self.dyn = None
 
     # ---- flat storage -----------------------------------------------------------------
     @staticmethod
@@ -112,6 +109,12 @@ class FusedAdam(Optimizer):
             self._prep_table = host.to(self.flat_p.device)
         ops.prepare_weights_batch(self._prep_table, n)
 
+    def invalidate_prepared(self):
+        """Call after ANY write to the weights that is not an optimizer step, a load_state_dict or an in-place op on the
+        parameter / the flat buffer itself (those are seen through the tensors' version counters): `p.data.copy_(...)`,
+        EMA through `.data`, a raw kernel.  Rebuilds every registered image from the current weights."""
+        self.refresh_prepared()
+
     # ---- optimizer API ----------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -119,21 +122,10 @@ class FusedAdam(Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        if self.dyn is not None:
-            ops.adam_step_graph(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["betas"][0], g["betas"][1],
-                                g["eps"], g["weight_decay"], self.dyn)
-        else:
-            self._step += 1
-            ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
-                          g["eps"], g["weight_decay"], self._step)
-        self.refresh_prepared()
-
-    def advance_dynamic(self):
-        """hipGraph mode: count the step on the host and hand the device its scalars (lr / (1 - beta1^t), sqrt(1 -
-        beta2^t)), ordered on the current stream before the replay."""
-        g = self.param_groups[0]
         self._step += 1
-        ops.adam_dynamic_scalars(g["lr"], g["betas"][0], g["betas"][1], self._step, self.dyn)
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
+                      g["eps"], g["weight_decay"], self._step)
+        self.refresh_prepared()
 
     def state_dict(self):
         state = {}
@@ -232,9 +224,7 @@ class _Branches:
 
     def adopt(self, *tensors):
         """Tensors that already exist on the caller's stream become usable on both branches: the fork in __init__ ordered
-        the branches behind the caller's stream, so only the allocator has to be told (no cross-over wait: besides being
-        redundant, a cross-over between two branches that hold no kernel yet is what hipStreamEndCapture of ROCm 7.2
-        crashes on when the step is captured into a graph)."""
+        the branches behind the caller's stream, so only the allocator has to be told."""
         if not self.enabled:
             return
         for t in tensors:
@@ -245,9 +235,7 @@ class _Branches:
     def share(self, *tensors):
         if not self.enabled:
             return
-        # cross-over = join into the caller's stream + fork again: the same ordering as a pairwise wait between the two
-        # branches, but built from the fork / join edges that a graph capture accepts (hipStreamEndCapture of ROCm 7.2
-        # crashes on a direct cross dependency between two forked streams); the caller's stream is idle meanwhile
+        # cross-over = join into the caller's stream + fork again (the caller's stream is idle meanwhile)
         for st in self.s:
             ops.stream_wait(self.main, st)
         for st in self.s:

@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the GPU suite: the fp32 hot path first (op parity, step parity, BASELINE-shape parity), then the
+# "next" rows (data pipeline, data parallel), the opt-in arithmetic modes last -- `pytest -x` (the driver's form) then reaches
+# every core parity test before anything optional can stop the run.
+_ORDER = ["test_gpu_ops", "test_gpu_step", "test_gpu_shapes", "test_gpu_data", "test_gpu_dp", "test_gpu_bf16s",
+          "test_gpu_bf16", "test_gpu_f32x3"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else -1       # CPU test files keep their place in front
+    items.sort(key=rank)                                          # stable: order inside a file is unchanged
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

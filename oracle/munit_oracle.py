@@ -52,12 +52,28 @@ class KinkMasks:
         self.masks, self.pos = list(masks), 0
         # the same for the L1 terms of the objective: recorded (input > target) patterns, in call order; None = plain abs
         self.l1_signs, self.l1_pos = (None if l1_signs is None else list(l1_signs)), 0
+        # where a recorded branch differs from the branch this (fp64) run would have taken by itself: the largest
+        # |pre-activation| among those elements relative to the tensor's max, and how many there are.  A recorded mask
+        # may only differ within rounding noise of the kink -- tests/parity.py asserts it (a wrong mask on a LARGE
+        # pre-activation would otherwise be followed, not flagged).
+        self.worst_rel, self.n_disagree, self.n_total, self.worst_at = 0.0, 0, 0, None
+
+    def _audit(self, own: Tensor, rec: Tensor, x: Tensor, where: str) -> None:
+        dis = own != rec
+        self.n_total += x.numel()
+        n = int(dis.sum())
+        if n:
+            self.n_disagree += n
+            rel = float(x.detach()[dis].abs().max()) / max(float(x.detach().abs().max()), 1e-300)
+            if rel > self.worst_rel:
+                self.worst_rel, self.worst_at = rel, where
 
     def take_l1(self, d: Tensor) -> Tensor:
         assert self.l1_pos < len(self.l1_signs), "more L1 terms than recorded sign patterns"
         m = self.l1_signs[self.l1_pos]
         self.l1_pos += 1
         assert tuple(m.shape) == tuple(d.shape), (self.l1_pos, tuple(m.shape), tuple(d.shape))
+        self._audit(d > 0, m, d, "l1 term %d" % (self.l1_pos - 1))
         return m
 
     def take(self, x: Tensor) -> Tensor:
@@ -65,7 +81,9 @@ class KinkMasks:
         m = self.masks[self.pos]
         self.pos += 1
         assert m.numel() == x.numel() and m.shape[0] == x.shape[0], (self.pos, tuple(m.shape), tuple(x.shape))
-        return m.reshape(x.shape)
+        m = m.reshape(x.shape)
+        self._audit(x > 0, m, x, "activation %d %s" % (self.pos - 1, tuple(x.shape)))
+        return m
 
     def done(self) -> bool:
         return self.pos == len(self.masks) and (self.l1_signs is None or self.l1_pos == len(self.l1_signs))

@@ -170,6 +170,53 @@ def test_checkpoint_names_and_key_layout(tmp_path):
         assert torch.equal(a, b)
 
 
+def ckpt_ref_hp():
+    """Hyper-parameters of the small geometry tests/golden/ckpt_ref was written for (make_golden_variants.py)."""
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_ref")
+    exp = json.load(open(os.path.join(here, "expect.json")))
+    hp = O.default_hp(32, 2, 1)
+    hp["gen"], hp["dis"] = dict(exp["gen_cfg"]), dict(exp["dis_cfg"])
+    return here, exp, hp
+
+
+def test_resume_loads_a_checkpoint_written_by_the_reference_modules():
+    """tests/golden/ckpt_ref holds gen_/dis_/optimizer.pt files produced by the REFERENCE's
+    AdaINGen_double / MsImageDis `state_dict()` and torch.optim.Adam `state_dict()` in the reference's save format
+    (scripts/trainer.py:1387-1429).  MUNIT_Trainer.resume must take them as they are (weights-only loader): key layout,
+    iteration count from the file name, parameter values, Adam moments and step counter."""
+    from munit_amd.trainer import MUNIT_Trainer
+    from tests.test_oracle_golden import close_digest, dg
+    here, exp, hp = ckpt_ref_hp()
+    tr = MUNIT_Trainer(hp)
+    assert list(tr.gen.state_dict().keys()) == exp["gen_keys"]
+    assert list(tr.dis_a.state_dict().keys()) == exp["dis_keys"]
+    assert tr.resume(here, hp) == exp["iterations"]
+    for p, d in zip(tr.gen.parameters(), exp["gen_params"]):
+        close_digest(dg(p), d, 1e-7)
+    assert tr.gen_opt._step == int(exp["gen_opt_step"]) == 2 and tr.dis_opt._step == 2
+    m0, _ = tr.gen_opt._views[0]
+    _, v_last = tr.gen_opt._views[-1]
+    close_digest(dg(m0), exp["gen_exp_avg0"], 1e-7)
+    close_digest(dg(v_last), exp["gen_exp_avg_sq_last"], 1e-7)
+    # and the files this build writes back carry the same keys and values (the reverse direction of the wire format)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.save(d, 2)
+        mine = torch.load(os.path.join(d, "gen_00000003.pt"), weights_only=True)["2"]
+        theirs = torch.load(os.path.join(here, "gen_00000003.pt"), weights_only=True)["2"]
+        assert list(mine) == list(theirs)
+        for k in mine:
+            assert mine[k].shape == theirs[k].shape and torch.equal(mine[k], theirs[k]), k
+        o_mine = torch.load(os.path.join(d, "optimizer.pt"), weights_only=True)
+        o_theirs = torch.load(os.path.join(here, "optimizer.pt"), weights_only=True)
+        for which in ("gen", "dis"):
+            assert set(o_mine[which]["state"]) == set(o_theirs[which]["state"])
+            for i, st in o_theirs[which]["state"].items():
+                assert torch.equal(o_mine[which]["state"][i]["exp_avg_sq"], st["exp_avg_sq"]), (which, i)
+                assert float(o_mine[which]["state"][i]["step"]) == float(st["step"])
+
+
 _DP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)

@@ -264,6 +264,72 @@ def test_checkpoint_roundtrip_on_device(tmp_path):
         assert torch.equal(p, q)
 
 
+def test_reference_written_checkpoint_runs_on_the_hip_path():
+    """The checkpoint written by the reference modules (tests/golden/ckpt_ref, see tests/test_cpu_host.py) loaded through
+    MUNIT_Trainer.resume and pushed through the HIP encoders / decoder / discriminator: outputs against the digests of the
+    reference modules' own fp32 forward on those weights (1e-4).  The geometry is deliberately small
+    and odd (dim 8: channel counts 8 / 16 / 32, a 2-scale 2-layer discriminator), i.e. off every fast path."""
+    from munit_amd.trainer import MUNIT_Trainer
+    from tests.test_cpu_host import ckpt_ref_hp
+    from tests.test_oracle_golden import close_digest, dg
+    here, exp, hp = ckpt_ref_hp()
+    tr = MUNIT_Trainer(hp)
+    assert tr.resume(here, hp) == exp["iterations"]
+    tr.to("cuda:0")
+    g = torch.Generator().manual_seed(exp["input_seed"])
+    x_a = 2 * torch.rand(*exp["input_shape"], generator=g) - 1
+    x_b = 2 * torch.rand(*exp["input_shape"], generator=g) - 1
+    with torch.no_grad():
+        c_a, _ = tr.gen.encode(x_a.cuda(), 1)
+        _, s_b = tr.gen.encode(x_b.cuda(), 2)
+        x_ab = tr.gen.decode(c_a, s_b, 2)
+        d = tr.dis_a(x_ab)
+    close_digest(dg(c_a), exp["content"], 1e-4)
+    close_digest(dg(s_b), exp["style"], 1e-4)
+    close_digest(dg(x_ab), exp["x_ab"], 1e-4)
+    assert len(d) == len(exp["dis"])
+    for o, e in zip(d, exp["dis"]):
+        close_digest(dg(o), e, 1e-4)
+    # one training step from the resumed state runs and keeps the step counters going
+    m = (torch.rand(2, 1, 32, 32, generator=g) > 0.5).float().cuda()
+    tr.update_learning_rate()
+    tr.dis_update(x_a.cuda(), x_b.cuda(), hp)
+    tr.gen_update(x_a.cuda(), x_b.cuda(), hp, m, m)
+    torch.cuda.synchronize()
+    assert tr.gen_opt._step == 3 and bool(torch.isfinite(tr.loss_gen_total))
+
+
+def test_prepared_weight_images_follow_out_of_band_weight_edits():
+    """Layers multiply by re-laid-out images of their weights (Winograd U, backward-data transposes) that the optimizer
+    refreshes after every step.  Edits that bypass the optimizer must not leave a stale image behind: an in-place write to the
+    flat parameter buffer (the form a broadcast takes) is caught by its version counter; a write through `.data` bumps no
+    counter and needs FusedAdam.invalidate_prepared() -- without it the stale image shows (which is what the call is for)."""
+    from munit_amd import ops
+    from munit_amd.trainer import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    w = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * 0.05).contiguous(memory_format=torch.channels_last))
+    opt = FusedAdam([w], lr=1e-2, betas=(0.5, 0.999), weight_decay=0.0)
+    opt.bind(torch.device("cuda:0"))
+    x = torch.randn(2, 64, 16, 16, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+
+    def fwd():
+        return ops.conv2d(x, w, None, 1, 1, "reflect", False, "none").detach().clone()
+
+    def ref():
+        return O.conv_block(x.double().cpu(), w.detach().double().cpu(), None, 1, 1, "reflect", None, "none")
+
+    y0 = fwd()
+    assert getattr(w, "_munit_prep"), "this layer is expected to run on a prepared (Winograd) image"
+    assert nerr(y0, ref()) <= 2e-5
+    with torch.no_grad():
+        opt.flat_p.mul_(2.0)                       # in-place on the flat buffer: seen through flat_p._version
+    assert nerr(fwd(), ref()) <= 2e-5 and nerr(fwd(), 2 * y0.double().cpu()) <= 2e-5
+    w.data.mul_(0.25)                              # through .data: no version counter moves
+    assert nerr(fwd(), ref()) > 1e-1               # stale image (documented hazard) ...
+    opt.invalidate_prepared()
+    assert nerr(fwd(), ref()) <= 2e-5              # ... until the images are rebuilt
+
+
 def test_hd_config_shapes_run():
     """BASELINE config #4 geometry (512x512, config_HD.yaml = same networks): encode/decode at full size vs
     the oracle (batch 1), then one full update with finite losses."""

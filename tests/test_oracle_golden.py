@@ -127,6 +127,42 @@ def test_step_matches_reference_sequence(golden, gs, iters):
             close_digest(dg(p), d_, 1e-9)
 
 
+@pytest.mark.parametrize("name", ["gs1_guided0", "gs0_guided0", "gs1_nomask"])
+def test_step_variants_match_reference_sequence(name):
+    """The branches make_golden.py's fixtures do not drive, pinned to the reference MODULES the same way
+    (tests/golden/make_golden_variants.py): `guided: 0` (sampled styles, trainer.py:377-379 / 405-407 / 438-440 /
+    1155-1157) for both generator layouts and `recon_mask: 0` (trainer.py:476-487): losses, every gradient tensor, weights
+    after one dis_update + gen_update, float64."""
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_variants.json")))[name]
+    hp = O.default_hp(rec["size"], rec["batch"], rec["gen_state"])
+    hp["guided"], hp["recon_mask"] = rec["guided"], rec["recon_mask"]
+    gen, dis_a, dis_b = states(hp, torch.float64)
+    tr = O.OracleTrainer(hp, gen, dis_a, dis_b)
+    x_a, x_b, m_a, m_b = (t.double() for t in O.synthetic_batch(rec["batch"], rec["size"], seed=7))
+    sd = hp["gen"]["style_dim"]
+
+    def styles(seed):       # the reference draws s_a, s_b at the top of each update from the host RNG (trainer.py:366-367)
+        torch.manual_seed(seed)
+        return torch.randn(rec["batch"], sd, 1, 1).double(), torch.randn(rec["batch"], sd, 1, 1).double()
+
+    tr.update_learning_rate()
+    dgr = tr.dis_update(x_a, x_b, *styles(rec["style_seeds"][0]))
+    ggr = tr.gen_update(x_a, x_b, m_a, m_b, *styles(rec["style_seeds"][1]))
+    for k, v in rec["losses"].items():
+        assert abs(float(tr.losses[k]) - v) <= 1e-9 * max(1.0, abs(v)), (k, float(tr.losses[k]), v)
+    for g_, d_ in zip(dgr, rec["dis_grad"]):
+        close_digest(dg(g_), d_, 1e-8, 1e-11)
+    for g_, d_ in zip(ggr, rec["gen_grad"]):
+        if d_ is not None:
+            close_digest(dg(g_), d_, 1e-8, 1e-11)
+    for p, d_ in zip(tr.opt["gen"]["params"], rec["gen_after"]):
+        close_digest(dg(p), d_, 1e-9)
+    for p, d_ in zip(tr.opt["dis"]["params"], rec["dis_after"]):
+        close_digest(dg(p), d_, 1e-9)
+
+
 def test_extraadam_matches_reference_file():
     """oracle ExtraAdamState vs the parameter trace produced by the reference's own
     scripts/extraadam.py (tests/golden/make_golden_extraadam.py)."""

@@ -11,9 +11,10 @@ recon_mask 1, aux losses 0), 256x256, batch 8, fp32.  N > 1 is weak scaling: eve
 per-GPU batch on its own shard of the global batch (data seed 7 + rank, identical model seed).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (Winograd F(2x2,3x3) conv of the residual trunk on v_mfma_f32_16x16x4_f32) measured
-                  with HIP events around its launches in extra instrumented steps of this same run; plus the
-                  step-level fractions on algorithmic and on executed FLOPs
+  roofline     -- the dominant kernel, chosen by measured time: every convolution pass (forward, backward-data,
+                  backward-weight) is bracketed by HIP events in extra instrumented steps of this same run; `frac` =
+                  executed FLOPs / duration / fp32 MFMA peak (<= 1), `algorithmic_frac` next to it, a top-3 table, and the
+                  step-level fractions on executed and on algorithmic FLOPs
   cpu_baseline -- the CPU oracle (oracle/munit_oracle.py, a torch-CPU restatement of the
                   reference step: kind "port") timed on this host's cores on a bounded sample
 """
@@ -31,10 +32,6 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (16x the fp32 matrix rate)
-KERNEL_NAMES = {
-    "conv_wino_kernel<fwd>": "conv_wino_kernel<0, 0> (Winograd F(2x2,3x3) forward of the 3x3 stride-1 layers on v_mfma_f32_16x16x4_f32)",
-    "conv_igemm_kernel<128,true,fwd>": "conv_igemm_kernel<128,true,fwd> (forward implicit-GEMM conv, Cout>64, Cin%32==0)",
-}
 GFLOP_PER_PAIR_256 = 2789.6   # algorithmic conv+linear FLOPs of dis_update+gen_update
 
 
@@ -63,7 +60,7 @@ def make_batch(batch, size, rank=0):
     return x_a, x_b, m_a, m_b
 
 
-PMC_SUMMARY = "profiles/r02_pmc_hbm_mfma.txt"
+PMC_SUMMARY = "profiles/r03_pmc_hbm_mfma.txt"
 
 
 def lib_fingerprint():
@@ -78,30 +75,42 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md; bench.py cannot collect PMC itself).
-    The summary records the fingerprint of the kernel sources it was collected on; when the sources have changed since,
-    the figure is stale and (None, why) is returned.  Returns (bytes, source)."""
-    path = os.path.join(ROOT, PMC_SUMMARY)
-    try:
-        lines = open(path).read().splitlines()
-    except OSError:
-        return None, "no PMC summary at %s" % PMC_SUMMARY
-    fp = [l.split()[-1] for l in lines if l.startswith("# kernel-source fingerprint:")]
-    if not fp or fp[0] != lib_fingerprint():
-        return None, "%s was collected on kernel sources %s, this run is %s: stale, not reported" % (
-            PMC_SUMMARY, fp[0] if fp else "unknown", lib_fingerprint())
-    try:
+class PmcSummary:
+    """HBM bytes per launch from the committed PMC summary (tools/pmc_step.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    separate passes, FETCH doubled per MI355X_MICROARCH.md; bench.py cannot collect PMC itself).  The summary records the
+    fingerprint of the kernel sources it was collected on; when the sources have changed since, the figures are stale and
+    nothing is reported (`why` says so)."""
+
+    def __init__(self):
+        self.rows, self.why, self.source = [], None, PMC_SUMMARY
+        try:
+            lines = open(os.path.join(ROOT, PMC_SUMMARY)).read().splitlines()
+        except OSError:
+            self.why = "no PMC summary at %s" % PMC_SUMMARY
+            return
+        fp = [l.split()[-1] for l in lines if l.startswith("# kernel-source fingerprint:")]
+        if not fp or fp[0] != lib_fingerprint():
+            self.why = "%s was collected on kernel sources %s, this run is %s: stale, not reported" % (
+                PMC_SUMMARY, fp[0] if fp else "unknown", lib_fingerprint())
+            return
+        import re
+        pat = re.compile(r"^(.*?)\s+blocks=\s*(\d+)\s+launches=\s*(\d+)\s+fetch\s+([\d.]+) MB\s+write\s+([\d.]+) MB")
         for line in lines:
-            if line.startswith("conv_wino_kernel<0, 0>") and "blocks=   512" in line:
-                f = line.split()
-                fetch = float(f[f.index("fetch") + 1])
-                write = float(f[f.index("write") + 1])
-                return int(round((fetch + write) * 1e6)), "%s (512-block launches: %.0f MB read + %.0f MB written)" % (PMC_SUMMARY, fetch, write)
-    except ValueError:
-        pass
-    return None, "dominant kernel not found in %s" % PMC_SUMMARY
+            m = pat.match(line)
+            if m:
+                self.rows.append((m.group(1).strip(), int(m.group(3)), float(m.group(4)) * 1e6, float(m.group(5)) * 1e6, int(m.group(2))))
+        if not self.rows:
+            self.why = "no kernel rows in %s" % PMC_SUMMARY
+
+    def lookup(self, kname, launches_per_step):
+        """(read bytes, written bytes) per launch of the kernel that leads the group `kname`, or None.  The PMC run holds 2
+        steps; a summary row is keyed by (kernel, total grid size), so it is used only when its launch count says it holds
+        exactly this group's launches (a row that mixes layer shapes is not attributed)."""
+        lead = kname.split(" + ")[0].split(" x4")[0].split(" (")[0].strip()
+        exact = [r for r in self.rows if r[0].startswith(lead[:40]) and r[1] == 2 * launches_per_step]
+        if len(exact) == 1:
+            return int(exact[0][2]), int(exact[0][3])
+        return None
 
 
 def host_cores():
@@ -229,7 +238,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher check only: gloo rendezvous on the CPU, no GPU work")
-    ap.add_argument("--no-modes", action="store_true", help="skip the supplementary timing of the opt-in f32x3 mode")
+    ap.add_argument("--no-modes", action="store_true", help="skip the supplementary timing of the opt-in reuse_dis_forward mode")
     ap.add_argument("--precision", choices=["f32", "bf16", "bf16s", "f32x3"], default="f32",
                     help="f32 = the reference's arithmetic (the headline metric, BASELINE.json configs[1]); "
                          "bf16s = configs[2] (use with --batch 32): bf16 storage of the trunk activations + bf16 MFMA, "
@@ -333,56 +342,81 @@ def main():
         step()                                   # also counts the FLOPs of one step, algorithmic and executed
         torch.cuda.synchronize()
         flops, ops.FLOPS = ops.FLOPS, None
+        n_prof = 2
         ops.PROFILE = []
-        for _ in range(2):
+        for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         ops.SIDE_STREAM_WGRAD, trainer_mod.BRANCH_STREAMS = saved
-        # dominant kernel = the variant with the most time in the step: the Winograd F(2x2,3x3) forward / backward-data
-        # kernel of the residual trunk (conv_wino.hip); the instrumentation tags its forward launches
-        by_tag = {}
-        for (tag, fl, fx, e0, e1) in recs:
-            by_tag.setdefault(tag, []).append((fl, fx, e0.elapsed_time(e1)))
-        dom = max(by_tag, key=lambda t: sum(r[2] for r in by_tag[t])) if by_tag else None
-        if "conv_wino_kernel<fwd>" in by_tag:
-            dom = "conv_wino_kernel<fwd>"
-        sel = by_tag.get(dom, [])
-        if sel and rank == 0:
-            tot_fl = sum(r[0] for r in sel)
-            tot_fx = sum(r[1] for r in sel)
-            tot_ms = sum(r[2] for r in sel)
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            ach_x = tot_fx / (tot_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic_bytes()
-            if (args.size, args.batch) != (256, 8):
-                traffic, traffic_src = None, "the committed PMC summary is of the 256x256 batch-8 workload"
+        # every convolution pass (forward / backward-data / backward-weight) of the two steps was bracketed by HIP events:
+        # group by (pass, kernel, layer geometry) and rank by measured time -- the dominant kernel is whatever comes out on top
+        groups = {}
+        for (which, pl, e0, e1) in recs:
+            g = groups.setdefault((which, pl.kname[which], pl.layer), {"n": 0, "ms": 0.0, "alg": 0.0, "exe": 0.0, "bytes": 0.0})
+            g["n"] += 1
+            g["ms"] += e0.elapsed_time(e1)
+            g["alg"] += pl.flop
+            g["exe"] += pl.flop_exec[which]
+            g["bytes"] += pl.bytes_alg[which]
+        ranked = sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+        if ranked and rank == 0:
+            pmc = PmcSummary() if (args.size, args.batch) == (256, 8) else None
+
+            def row(key, g):
+                which, kname, layer = key
+                sec_ = g["ms"] * 1e-3
+                r = {"kernel": kname, "pass": ("forward", "backward-data", "backward-weight")[which], "layer": layer,
+                     "launches_per_step": g["n"] // n_prof, "avg_launch_us": round(1e3 * g["ms"] / g["n"], 2),
+                     "ms_per_step": round(g["ms"] / n_prof, 3),
+                     "executed_frac": round(g["exe"] / sec_ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "algorithmic_frac": round(g["alg"] / sec_ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic_algorithmic": int(g["bytes"] / g["n"])}
+                t = pmc.lookup(kname, g["n"] // n_prof) if pmc is not None else None
+                r["traffic"] = None if t is None else t[0] + t[1]
+                r["traffic_over_algorithmic"] = None if t is None else round((t[0] + t[1]) / r["traffic_algorithmic"], 2)
+                if t is not None:
+                    r["traffic_read_write"] = [t[0], t[1]]
+                return r
+
+            top = [row(k, g) for k, g in ranked[:3]]
+            key, g = ranked[0]
+            d = top[0]
             sec = ms_per_step * 1e-3
+            exe_tf = g["exe"] / (g["ms"] * 1e-3) / 1e12
+            alg_tf = g["alg"] / (g["ms"] * 1e-3) / 1e12
+            traffic_src = (pmc.source if pmc is not None and d["traffic"] is not None else
+                           (pmc.why if pmc is not None else "the committed PMC summary is of the 256x256 batch-8 workload"))
             out["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": KERNEL_NAMES.get(dom, dom),
-                # the same launches priced on the FLOPs the kernel really issues on the matrix pipe: Winograd F(2x2,3x3)
-                # spends 16 multiply-accumulates where the algorithmic count (the contract's numerator) has 36, so
-                # `frac` can exceed 1 while the pipe itself runs at `executed_frac` of its peak
-                "executed_achieved": round(ach_x, 2), "executed_frac": round(ach_x / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": ("frac is priced on algorithmic FLOPs as the contract asks; the kernel is Winograd F(2x2,3x3), which issues "
-                         "16 of every 36 algorithmic multiply-accumulates, so frac > 1 is expected -- executed_frac prices the "
-                         "same launches on the FLOPs actually issued on the fp32 matrix pipe") if ach_x < ach else "",
-                "launches_per_step": len(sel) // 2, "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
-                "algorithmic_gflop_per_launch_avg": round(tot_fl / len(sel) / 1e9, 3),
-                "executed_gflop_per_launch_avg": round(tot_fx / len(sel) / 1e9, 3),
-                "method": "HIP events around every launch of the kernel in 2 extra instrumented steps after "
-                          "the timed region, run on a single stream (the timed region overlaps kernels on 3 streams, "
-                          "see step_frac); algorithmic FLOPs = 2*B*Ho*Wo*Cout*KH*KW*Cin per launch",
-                "step_achieved": round(step_flop / sec / 1e12, 2),
-                "step_frac": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "step_algorithmic_tflop": round(step_flop / 1e12, 3),
-                # the same step counted launch by launch: algorithmic (cross-check of SURVEY.md 8d's figure) and the FLOPs
-                # the kernels really issue (sub-pixel up-sampling convs and box-sum backward-data execute fewer)
-                "step_counted_algorithmic_tflop": round(flops["alg"] / 1e12, 3),
+                # `achieved` / `frac` price the dominant kernel on the FLOPs it ISSUES on the fp32 matrix pipe, so frac <= 1 is
+                # a pipe utilisation; the ALGORITHMIC pricing (2*B*Ho*Wo*Cout*KH*KW*Cin per launch) stands next to
+                # it: Winograd kernels issue 16 of every 36 algorithmic multiply-accumulates, so algorithmic_frac can exceed 1
+                "bound": "mfma", "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "algorithmic_achieved": round(alg_tf, 2), "algorithmic_frac": round(alg_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": d["traffic"], "traffic_algorithmic": d["traffic_algorithmic"],
+                "traffic_over_algorithmic": d["traffic_over_algorithmic"], "traffic_source": traffic_src,
+                "kernel": d["kernel"], "pass": d["pass"], "layer": d["layer"],
+                "selection": "largest total measured time among all (pass, kernel, layer) groups of the instrumented steps",
+                "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_launch_us"], "ms_per_step": d["ms_per_step"],
+                "algorithmic_gflop_per_launch_avg": round(g["alg"] / g["n"] / 1e9, 3),
+                "executed_gflop_per_launch_avg": round(g["exe"] / g["n"] / 1e9, 3),
+                "method": "HIP events on the launch stream around every convolution pass (forward, backward-data, backward-weight) "
+                          "in %d extra instrumented steps after the timed region, run on a single stream (the timed region "
+                          "overlaps kernels on 3 streams); traffic = rocprofv3 --pmc FETCH_SIZE (doubled, gfx950) + WRITE_SIZE "
+                          "per launch from the committed summary when its kernel-source fingerprint matches this build; "
+                          "traffic_algorithmic = input + weight + output tensors once" % n_prof,
+                "top": top,
+                # step level: executed FLOPs of the whole step / step time / peak, and the algorithmic figure next to it
+                "step_frac": round(flops["exec"] / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_achieved": round(flops["exec"] / sec / 1e12, 2),
                 "step_executed_tflop": round(flops["exec"] / 1e12, 3),
-                "step_executed_frac": round(flops["exec"] / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_algorithmic_frac": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_algorithmic_achieved": round(step_flop / sec / 1e12, 2),
+                "step_algorithmic_tflop": round(step_flop / 1e12, 3),
+                # the same step counted launch by launch (cross-check of SURVEY.md 8d's analytic figure)
+                "step_counted_algorithmic_tflop": round(flops["alg"] / 1e12, 3),
+                "conv_ms_per_step_single_stream": round(sum(g_["ms"] for g_ in groups.values()) / n_prof, 2),
             }
     if rank == 0 and args.precision in ("bf16", "bf16s") and not args.no_roofline:
         # build extension (no reference counterpart): step-level fraction against the dense bf16 MFMA peak and, for
@@ -395,33 +429,9 @@ def main():
                            "step_frac_vs_f32_mfma_peak": round(step_flop / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                            "step_algorithmic_tflop": round(step_flop / 1e12, 3)}
     if rank == 0 and world == 1 and args.precision == "f32" and not args.no_modes:
-        # supplementary, NOT the metric: the same step in the opt-in f32x3 mode (fp32 operands split exactly into three
-        # bf16 planes, six product terms, fp32 accumulate; passes the fp32 parity tests at unchanged tolerances)
         del trainer
         torch.cuda.empty_cache()
-        hp2 = dict(hp)
-        hp2["precision"] = "f32x3"
-        torch.manual_seed(1234)
-        tr2 = MUNIT_Trainer(hp2)
-        tr2.to(dev)
-
-        def step2():
-            tr2.update_learning_rate()
-            tr2.dis_update(x_a, x_b, hp2)
-            tr2.gen_update(x_a, x_b, hp2, m_a, m_b)
-        for _ in range(2):
-            step2()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            step2()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
-        out["other_modes"] = {"f32x3": {"ms_per_step": round(1e3 * dt, 3), "images_per_s": round(args.batch / dt, 3),
-                                        "note": "opt-in; not the reported metric"}}
-        del tr2
-        ops.set_compute("f32")
-        torch.cuda.empty_cache()
+        out["other_modes"] = {}
         # supplementary, NOT the metric: fp32 with `reuse_dis_forward: 1` -- gen_update continues from the generator forward
         # that dis_update ran on the same batch instead of recomputing it as the reference does (same losses bit for
         # bit, gradients to fp32 summation order, 11 % fewer multiply-accumulates)

@@ -154,6 +154,10 @@ int munit_linear_bwd(const float* x, const float* w, const float* dy, float* dx,
  * the padded domain and the 4-channel re-layout of the 3-channel image layers slightly more.  Measurement only
  * (bench.py: roofline.step_executed_tflop). */
 double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass);
+/* Name, as rocprofv3 shows it, of the kernel (or kernel group) that carries `pass` of this layer: the dispatch of the three
+ * entry points stated as text.  Measurement only (bench.py picks the dominant kernel of the step by measured time and names
+ * it with this). Static storage; never NULL. */
+const char* munit_conv2d_kernel_name(const munit_conv_desc* d, int pass);
 
 /* dx = dy * act'(y) for the fused activations (y = post-activation output). n elements. */
 int munit_act_bwd(int act, float slope, const float* y, const float* dy, float* dx, size_t n,

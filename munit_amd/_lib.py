@@ -61,6 +61,7 @@ SIGNATURES = {
     "munit_conv2d_fwd_prepared": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "munit_conv2d_dgrad_prepared": (c_int, [_DESC, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "munit_conv2d_executed_flops": (c_double, [_DESC, c_int]),
+    "munit_conv2d_kernel_name": (c_char_p, [_DESC, c_int]),
     "munit_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "munit_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
     "munit_linear_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),

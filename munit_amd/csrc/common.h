@@ -84,6 +84,7 @@ __device__ inline int src_coord(int v, int Hu, int ups, int reflect) {
 
 // conv_igemm.hip: executed (not algorithmic) FLOPs of the forward / backward-data pass of a layer
 double munit_igemm_executed_flops(const munit_conv_desc* d, int pass);
+const char* munit_igemm_kernel_name(const munit_conv_desc* d, int pass);
 
 // conv_small.hip: channel-per-lane kernels for convolutions with 3 channels on one side
 bool munit_small_fwd_supported(const munit_conv_desc* d);

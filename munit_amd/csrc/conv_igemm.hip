@@ -1850,6 +1850,34 @@ extern "C" int munit_conv2d_prepare_weights_batch(const munit_prep_item* items_d
 // 2*B*Ho*Wo*Cout*KH*KW*Cin: the sub-pixel forward runs 4 merged 3x3 phases + the 25-tap frame, the box-sum
 // backward-data one 25-tap row per interior SOURCE pixel + the frame, strided backward-data its phases over the
 // padded domain.  Valid GEMM rows only (tile padding is not counted).  bench.py reports both totals.
+// Name (as a profiler shows it) of the kernel that carries a pass of this layer; mirrors the dispatch of the entry points.
+const char* munit_igemm_kernel_name(const munit_conv_desc* d, int pass) {
+  int Ho, Wo;
+  if (munit_conv2d_out_hw(d, &Ho, &Wo)) return "invalid";
+  const bool refl = d->pad_mode == MUNIT_PAD_REFLECT;
+  if (pass == MUNIT_PASS_FWD) {
+    if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return "conv_head_pk_kernel";
+    if (subpixel_wino_ok(d)) return "conv_wino_kernel<1, 0> x4 sub-pixel phases + conv_igemm_kernel frame";
+    if (subpixel_ok(d)) return "conv_igemm_kernel x4 sub-pixel phases + frame";
+    if (wino_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 0>" : "conv_wino_kernel<1, 0>";
+    if (wino_s2_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 1>" : "conv_wino_kernel<1, 1>";
+    if (cin4_fwd_ok(d)) return "conv_igemm_kernel<.., 5> (3 input channels as 4-channel taps)";
+    return "conv_igemm_kernel<fwd>";
+  }
+  DgradPlan pl;
+  if (plan_dgrad(d, &pl)) return "invalid";
+  if (pl.wino) return refl ? "conv_wino_kernel<2, 0>" : "conv_wino_kernel<1, 0>";
+  if (pl.wino_s2) return refl ? "conv_wino_kernel<0, 2>" : "conv_wino_kernel<1, 2>";
+  if (pl.boxsum && pl.upwino) return "conv_wino_kernel<1, 3> + conv_igemm_kernel frame";
+  if (pl.boxsum) return "box2x2_kernel + conv_igemm_kernel (box-sum backward-data)";
+  if (pl.small) return "conv_head_pk_kernel (padded-domain correlation)";
+  if (pl.patch) return "conv_igemm_kernel<.., 2, 3> (LDS-patch fold)";
+  if (pl.folded) return "conv_igemm_kernel<.., 2, 0> (folded gather)";
+  if (pl.direct) return "conv_igemm_kernel<dgrad direct>";
+  if (pl.cin4) return "conv_igemm_kernel<.., 1, 5> (3 output channels as 4-channel taps)";
+  return "conv_igemm_kernel<.., 1, .> phases + fold_kernel";
+}
+
 double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   int Ho, Wo;
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;

@@ -1143,6 +1143,22 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   return cc * d->B * Ho * Wo * d->KH * d->KW;
 }
 
+extern "C" const char* munit_conv2d_kernel_name(const munit_conv_desc* d, int pass) {
+  if (pass == MUNIT_PASS_FWD || pass == MUNIT_PASS_DGRAD) return munit_igemm_kernel_name(d, pass);
+  int Ho, Wo;
+  if (pass != MUNIT_PASS_WGRAD || munit_conv2d_out_hw(d, &Ho, &Wo)) return "invalid";
+  if (wino_s2_wgrad_layer(d)) return "conv_wino_wgrad_kernel<true> + wino_wgrad_reduce_kernel";
+  if (wino_wgrad_layer(d)) return "conv_wino_wgrad_kernel<false> + wino_wgrad_reduce_kernel";
+  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return "conv_lanes_wgrad_kernel";
+  if (subpixel_wgrad_ok(d)) {
+    SubpixelPlan sp;
+    plan_subpixel(d, &sp);
+    return sp.wino ? "conv_wino_wgrad_kernel<false> x4 sub-pixel phases + frame + reduce" : "conv_wgrad_kernel x4 sub-pixel phases + frame";
+  }
+  if (cin3_padded_ok(d)) return "conv_wgrad_kernel (3 input channels padded to 4)";
+  return "conv_wgrad_kernel + slab_reduce_kernel";
+}
+
 extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const void* dy, float* dw,
                                   float* db, float beta, void* ws, size_t ws_bytes,
                                   munit_stream_t stream) {

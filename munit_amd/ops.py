@@ -20,8 +20,8 @@ from . import _lib
 from ._lib import ACT, COMPUTE, PAD, ConvDesc
 
 _ws_cache = {}
-# bench.py sets this to a list to time every forward-conv launch with HIP events on the launch stream:
-# entries are (kernel variant tag, algorithmic FLOPs, executed FLOPs, start event, end event).
+# bench.py sets this to a list to time every convolution pass (forward, backward-data, backward-weight) with HIP events on
+# the launch stream: entries are (pass 0/1/2, the layer's _Plan, start event, end event).
 PROFILE = None
 # tests/parity.py sets this to a list to record, in call order, the sign pattern (output > 0) behind every ReLU /
 # LeakyReLU of a forward pass, so that the fp64 oracle can take the same branch at every kink.
@@ -131,8 +131,8 @@ class _Plan(object):
     """Everything about one layer geometry that does not change between calls: the descriptor, output extent,
     workspace sizes and prepared-weight sizes of the three passes.  Built once per (shape, config) -- the C-ABI
     queries behind it cost more host time than the launch itself when they are repeated ~500 times per step."""
-    __slots__ = ("d", "ref", "ho", "wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "prep_bytes", "prep_sig", "tag", "flop",
-                 "flop_exec")
+    __slots__ = ("d", "ref", "ho", "wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "prep_bytes", "prep_sig", "kname", "layer", "flop",
+                 "flop_exec", "bytes_alg")
 
 
 _plans = {}
@@ -163,13 +163,12 @@ def _plan(b, h, w, cin, cout, kh, kw, stride, pad, pad_type, upsample, act="none
         rc = lib.munit_conv2d_prep_item(pl.ref, which, None, None, byref(item))
         sig.append((which, item.kind, item.ps, item.bf16) if rc == 0 else (which, 0, 0, 0))
     pl.prep_sig = tuple(sig)
-    pl.tag = "conv_igemm_kernel<%d,%s,fwd>" % (64 if cout <= 64 else 128, "true" if cin % 32 == 0 else "false")
-    if pl.prep_sig[0][1] == 4:                 # MUNIT_PREP_WINOGRAD: the forward is one launch of conv_wino.hip
-        pl.tag = "conv_wino_kernel<fwd>"
-    elif pl.ws_fwd:
-        pl.tag = "multi_kernel_conv"           # sub-pixel upsample conv or split-K (+ epilogue): not one launch
-    elif cout <= 4:
-        pl.tag = "conv_patch_fwd_kernel"
+    # measurement only (bench.py): profiler name of the kernel behind each pass, a readable layer label, and the
+    # algorithmic HBM bytes of a pass = its operand tensors once (fwd: x + w + y; dgrad: dy + w + dx; wgrad: x + dy + dw)
+    pl.kname = tuple(lib.munit_conv2d_kernel_name(pl.ref, k).decode() for k in range(3))
+    pl.layer = "%s%dx%d s%d %d->%d @%dx%d B=%d" % ("up x2 + " if upsample else "", kh, kw, stride, cin, cout, h, w, b)
+    nx, ny, nw = b * h * w * cin * (2 if in_dt else 4), b * pl.ho * pl.wo * cout * (2 if out_dt else 4), cout * kh * kw * cin * 4
+    pl.bytes_alg = (nx + nw + ny,) * 3
     pl.flop = 2.0 * b * pl.ho * pl.wo * cout * kh * kw * cin        # algorithmic, the same for all three passes
     pl.flop_exec = tuple(lib.munit_conv2d_executed_flops(pl.ref, k) for k in range(3))
     _plans[key] = pl
@@ -295,7 +294,7 @@ def conv2d_fwd_raw(x, weight, bias, stride, pad, pad_type, upsample, act, slope=
                                                  ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
         if PROFILE is not None:
             e1.record()
-            PROFILE.append((pl.tag, pl.flop, pl.flop_exec[0], e0, e1))
+            PROFILE.append((0, pl, e0, e1))
         _count(pl, 0)
     if MASK_SINK is not None and act in ("relu", "lrelu"):
         MASK_SINK.append(y > 0)
@@ -317,8 +316,14 @@ def conv2d_dgrad_raw(dy, weight, x_shape, stride, pad, pad_type, upsample, add=N
         if add is not None:
             add = nhwc(add)
         wp = _prepared(owner, weight, pl, 1)
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.munit_conv2d_dgrad_prepared(pl.ref, _p(dy), _p(weight), _p(wp), _p(add), _p(dx), _p(ws),
                                                    ws.numel(), _stream()), "conv2d_dgrad")
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append((1, pl, e0, e1))
         _count(pl, 1)
     return dx
 
@@ -344,8 +349,15 @@ def conv2d_wgrad_raw(x, dy, weight_shape, stride, pad, pad_type, upsample, dw=No
         if db is None and want_bias:
             db = torch.empty(cout, device=x.device, dtype=torch.float32)
         st = _stream() if stream is None else c_void_p(stream.cuda_stream)
+        prof = PROFILE is not None and stream is None       # bench.py's instrumented steps run on one stream
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.munit_conv2d_wgrad(pl.ref, _p(x), _p(dy), _p(dw), _p(db), c_float(beta), _p(ws), ws.numel(), st),
                    "conv2d_wgrad")
+        if prof:
+            e1.record()
+            PROFILE.append((2, pl, e0, e1))
         _count(pl, 2)
     return dw, db
 

@@ -40,6 +40,15 @@ static_assert(WINO_SMEM >= 2 * VBUF, "operand buffers must fit");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Diagnostic build only (make alt ALTFLAGS=-DWINO_STAMP, tools/wino_stamps.py): per-wave cycle accounting of the main loop with
+// s_memtime; nothing of it exists in the product library.
+#ifdef WINO_STAMP
+__device__ long long g_wino_stamps[8 * 8 * 4];   // [block < 8][wave][segment]
+#define WSTAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
+
 // none / ReLU / LeakyReLU (tanh layers have 3 output channels and never come here)
 __device__ inline float wino_act(float v, int act, float slope) {
   return act == MUNIT_ACT_NONE ? v : (v > 0.f ? v : (act == MUNIT_ACT_RELU ? 0.f : v * slope));
@@ -88,7 +97,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   const int b = m_blk / p.bth;
 
   // ---- loader (waves 0-3 only): thread = (tile tl, channel pair cp of the chunk); waves 4-7 only multiply ----
+#ifdef WINO_SWAP_ROLES      // experiment: the second-dispatched half of the block loads and transforms
+  const bool loader = wave >= 4;
+#else
   const bool loader = wave < 4;
+#endif
+#if defined(WINO_PRIO) && WINO_PRIO == 1
+  if (!loader) __builtin_amdgcn_s_setprio(1);
+#elif defined(WINO_PRIO) && WINO_PRIO == 2
+  if (loader) __builtin_amdgcn_s_setprio(1);
+#endif
   const int tl = (tid & 255) >> 2, cp = tid & 3;
   // tile of this loader thread, clamped (stores are predicated).  3x3 layers: 8x8 tiles of image b; S2: 64 consecutive tiles
   // of the batch-wide list (b, ty, tx) -- 3x3-pixel tiles rarely divide the extent, and whole 8x8 blocks would waste up to a
@@ -238,6 +256,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   // layer is not L2-resident as it is in a back-to-back timing loop, and a request issued only at the start of its own chunk
   // (tried for the loader waves, which are short of registers) made the step 1.4 % slower while the loop timing improved.
   const int nc = p.K / WK;
+#ifdef WINO_STAMP
+  long long st_acc[4] = {0, 0, 0, 0};
+  long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   if (loader) {
     UFrag u0, u1;
     load_raw(0);
@@ -245,14 +267,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     transform_store(0);
     if (nc > 1) load_raw(1);
     __syncthreads();
+    WSTAMP(3);
     auto body = [&](int c, int cur, const UFrag& u, UFrag& un) {
       if (c + 1 < nc) {
         load_u(c + 1, un);
         transform_store(cur ^ 1);
         if (c + 2 < nc) load_raw(c + 2);
       }
+      WSTAMP(0);
       compute(cur, u);
+      WSTAMP(1);
       __syncthreads();
+      WSTAMP(2);
     };
     for (int c = 0; c < nc; c += 2) {
       body(c, 0, u0, u1);
@@ -262,17 +288,28 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     UFrag u0, u1;
     load_u(0, u0);
     __syncthreads();
+    WSTAMP(3);
     for (int c = 0; c < nc; c += 2) {
       if (c + 1 < nc) load_u(c + 1, u1);
+      WSTAMP(0);
       compute(0, u0);
+      WSTAMP(1);
       __syncthreads();
+      WSTAMP(2);
       if (c + 1 < nc) {
         if (c + 2 < nc) load_u(c + 2, u0);
+        WSTAMP(0);
         compute(1, u1);
+        WSTAMP(1);
         __syncthreads();
+        WSTAMP(2);
       }
     }
   }
+#ifdef WINO_STAMP
+  if (blockIdx.x < 8 && blockIdx.y == 0 && lane == 0)
+    for (int i = 0; i < 4; ++i) g_wino_stamps[(blockIdx.x * 8 + wave) * 4 + i] = st_acc[i];
+#endif
   // ---- epilogue: M[f][tile][32 channels] planes through LDS, two halves ----
   const int co = tid & 31;
   const float slope = p.slope;
@@ -696,6 +733,12 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, const f
 }
 
 }  // namespace
+
+#ifdef WINO_STAMP
+extern "C" int munit_debug_wino_stamps(long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamps), sizeof(long long) * 8 * 8 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool munit_wino_wgrad_ok(int B, int H, int W, int Cin, int Cout) {
   if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD") || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD_WGRAD")) return false;

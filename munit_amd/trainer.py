@@ -84,7 +84,23 @@ class FusedAdam(Optimizer):
                 views.append((self._view(flat_m, off, p), self._view(flat_v, off, p)))
         self.flat_p, self.flat_g, self.flat_m, self.flat_v = flat_p, flat_g, flat_m, flat_v
         self._views = views
+        self._offsets = offs                  # start of every parameter in the flat buffers (16-byte aligned slots)
+        self._total = total
         self._prep_items, self._prep_table = [], None
+
+    def ranges_of(self, select):
+        """Maximal contiguous [start, end) element ranges of the flat buffers covered by the parameters p with
+        select(p) true, in buffer order (alignment gaps between two selected parameters belong to the range)."""
+        out = []
+        ends = self._offsets[1:] + [self._total]
+        for p, a, b in zip(self._plist, self._offsets, ends):
+            if not select(p):
+                continue
+            if out and out[-1][1] == a:
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        return [tuple(r) for r in out]
 
     # ---- prepared weight images ----------------------------------------------------------
     def register_prepared(self, item):
@@ -192,6 +208,100 @@ class FusedExtraAdam(FusedAdam):
 
 
 FORCE_ALLREDUCE = bool(os.environ.get("MUNIT_FORCE_ALLREDUCE"))
+# Data-parallel exchange of the generator gradient in two parts (SURVEY.md section 8e "launch on a side stream to overlap
+# with the remaining backward"): see GradExchange.  MUNIT_NO_OVERLAP_EXCHANGE=1 = one all-reduce after backward (A/B, tests).
+OVERLAP_EXCHANGE = not os.environ.get("MUNIT_NO_OVERLAP_EXCHANGE")
+
+
+def dp_world():
+    """World size of the data-parallel exchange, 0 when no exchange is to be issued (no process group, or a single rank
+    without MUNIT_FORCE_ALLREDUCE)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size()
+    return world if (world > 1 or FORCE_ALLREDUCE) else 0
+
+
+class GradExchange:
+    """All-reduce (mean) of a flat gradient buffer in two parts.
+
+    Every generator weight is used by several sub-graph calls (4 encodes, 6 decodes per gen_update), so a gradient is final only
+    when the LAST backward pass through its module has run.  Backward replays the forward in reverse: the decoders' and the
+    MLPs' last use is the pair of decodes right after the first encodes, so their gradients -- `early`, about half of the flat
+    buffer -- are final when the gradients of the first encodes' outputs (c_a, c_b, s_a', s_b') have been formed, while the
+    backward of those two encodes (about 8 % of the backward pass) is still to come.  `arm(tensors)` hooks those tensors; when
+    the last hook fires, a communication stream is ordered behind everything enqueued so far on the producing streams and the
+    early ranges are all-reduced from it, asynchronously.  `finish()` (after backward, on the caller's stream) reduces the rest,
+    waits for the early part and scales by 1 / world.
+
+    Every rank issues the same collectives in the same order (early ranges in buffer order, then the rest in buffer order).
+    Each element is summed over the ranks exactly once either way; with two ranks the result is bitwise the single all-reduce's
+    (tests), with more ranks it can differ in the last bit where the ring's chunk boundaries move -- as between any two bucket
+    layouts."""
+
+    _comm = {}
+
+    def __init__(self, flat, early, world, streams=()):
+        self.flat, self.world = flat, world
+        self.early = [r for r in early if r[1] > r[0]]
+        rest, pos = [], 0
+        for a, b in self.early:
+            if a > pos:
+                rest.append((pos, a))
+            pos = b
+        if pos < flat.numel():
+            rest.append((pos, flat.numel()))
+        self.rest = rest
+        self.streams = [s for s in streams if s is not None]
+        self.works, self.pending, self.fired = [], 0, False
+
+    def arm(self, tensors):
+        ts = [t for t in tensors if torch.is_tensor(t) and t.requires_grad]
+        self.pending = len(ts)
+        for t in ts:
+            t.register_hook(self._hook)
+        return self
+
+    def _hook(self, grad):
+        self.pending -= 1
+        if self.pending == 0:
+            self._launch_early()
+        return None
+
+    def _launch_early(self):
+        import torch.distributed as dist
+        self.fired = True
+        if self.flat.is_cuda:
+            dev = self.flat.device
+            key = (dev.type, dev.index)
+            if key not in GradExchange._comm:
+                GradExchange._comm[key] = torch.cuda.Stream(device=dev)
+            comm = GradExchange._comm[key]
+            for st in self.streams:           # everything that writes the early ranges has been enqueued on these by now
+                ops.stream_wait(comm, st)
+            with torch.cuda.stream(comm):
+                for a, b in self.early:
+                    self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
+        else:
+            for a, b in self.early:
+                self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
+
+    def finish(self):
+        """Call on the stream that holds the complete gradient (after backward and the joins of the producing streams)."""
+        import torch.distributed as dist
+        if not self.fired:                    # hooks never fired (no tensor required grad): everything goes now
+            self.rest, self.early = [(0, self.flat.numel())], []
+        for a, b in self.rest:
+            dist.all_reduce(self.flat[a:b])
+        for w in self.works:
+            w.wait()                          # on a device: the caller's stream waits for the communication stream
+        if self.world > 1:
+            if self.flat.is_cuda:
+                ops.scale_(self.flat, 1.0 / self.world)
+            else:
+                self.flat.mul_(1.0 / self.world)
+
 BRANCH_STREAMS = not os.environ.get("MUNIT_NO_BRANCH_STREAMS")   # bench.py clears it while it times single kernels
 
 
@@ -361,6 +471,10 @@ class MUNIT_Trainer(nn.Module):
         self.dis_opt.bind(device)
         self.gen_opt.bind(device)
         self._consts = {}
+        # flat-gradient ranges of the decoders and MLPs (final before the first encodes' backward: GradExchange)
+        gens = [self.gen] if self.gen_state == 1 else [self.gen_a, self.gen_b]
+        early = {id(p) for g in gens for n, p in g.named_parameters() if n.startswith("dec") or n.startswith("mlp")}
+        self._early_ranges = self.gen_opt.ranges_of(lambda p: id(p) in early)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -428,10 +542,8 @@ class MUNIT_Trainer(nn.Module):
         """Data-parallel exchange: one all-reduce (RCCL over xGMI) of the flat gradient.  MUNIT_FORCE_ALLREDUCE=1
         issues it at world size 1 too (a 1-GPU box then exercises the RCCL path; the result is unchanged)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        world = dist.get_world_size()
-        if world > 1 or FORCE_ALLREDUCE:
+        world = dp_world()
+        if world:
             dist.all_reduce(flat)
             if world > 1:
                 if flat.is_cuda:
@@ -534,10 +646,23 @@ class MUNIT_Trainer(nn.Module):
                       (hp["recon_x_cyc_w"], self.loss_gen_cycrecon_x_b)]
         self.loss_gen_total = ops.weighted_sum([t.detach() for _, t in pairs], [w for w, _ in pairs])
         live = [(w, t) for w, t in pairs if w != 0 and t.requires_grad]
+        world = dp_world()
+        xch = None
+        if world and OVERLAP_EXCHANGE:
+            # the decoder / MLP half of the flat gradient is exchanged while the first encodes' backward still runs
+            streams = [torch.cuda.current_stream(dev)] if dev.type == "cuda" else []
+            if br.enabled:
+                streams += list(br.s)
+            if dev.type == "cuda" and ops.SIDE_STREAM_WGRAD:
+                streams.append(ops._side_stream(dev))
+            xch = GradExchange(self.gen_opt.flat_g, self._early_ranges, world, streams).arm([c_a, c_b, s_a_prime, s_b_prime])
         torch.autograd.backward([t for _, t in live], [self._const(w, dev) for w, _ in live])
         br.join()                        # the backward pass ran on the branch streams its nodes were recorded on
         ops.join_side_streams()          # backward-weight kernels run on a side stream
-        self._all_reduce_mean(self.gen_opt.flat_g)
+        if xch is not None:
+            xch.finish()
+        else:
+            self._all_reduce_mean(self.gen_opt.flat_g)
         self.gen_opt_step()
         self._log(comet_exp, ("loss_gen_adv_a", "loss_gen_adv_b", "loss_gen_recon_x_a", "loss_gen_recon_s_a",
                               "loss_gen_recon_c_a", "loss_gen_recon_x_b", "loss_gen_recon_s_b",

@@ -256,6 +256,84 @@ def test_data_parallel_exchange_gloo_world2(tmp_path):
         assert p.returncode == 0, o
 
 
+_XCH_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from munit_amd import trainer as T
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+r = dist.get_rank()
+n = 1000
+g = torch.Generator().manual_seed(50 + r)
+grad = torch.randn(n, generator=g)                       # this rank's "flat gradient"
+early = [(300, 520), (700, 1000)]                        # two ranges, as gen_state 0 has (decoder + MLP of gen_a and of gen_b)
+# serial form: one all-reduce of the whole buffer
+serial = grad.clone()
+T.MUNIT_Trainer._all_reduce_mean(serial)
+# overlapped form: the early ranges go out from a tensor hook in the middle of a backward pass, the rest afterwards
+flat = grad.clone()
+enc_w = torch.ones(4, requires_grad=True)
+dec_w = torch.ones(4, requires_grad=True)
+c = enc_w * 3.0                                           # "content code": its gradient is formed after the decoder's
+fired_at = []
+xch = T.GradExchange(flat, early, T.dp_world()).arm([c])
+enc_w.register_hook(lambda g_: fired_at.append(("enc", xch.fired)))
+loss = (dec_w * c).sum()
+loss.backward()
+assert xch.fired and fired_at == [("enc", True)], fired_at   # the exchange was launched BEFORE the encoder's gradient existed
+assert xch.rest == [(0, 300), (520, 700)], xch.rest
+xch.finish()
+assert torch.equal(flat, serial), (flat - serial).abs().max()
+# a graph in which no hooked tensor needs a gradient: everything is exchanged in finish()
+flat2 = grad.clone()
+x2 = T.GradExchange(flat2, early, T.dp_world()).arm([torch.ones(3)])
+x2.finish()
+assert torch.equal(flat2, serial)
+other = [torch.zeros(n) for _ in range(2)]
+dist.all_gather(other, grad)
+assert torch.allclose(serial, (other[0] + other[1]) / 2)
+dist.barrier()
+dist.destroy_process_group()
+print("ok", r)
+"""
+
+
+def test_overlapped_gradient_exchange_equals_the_serial_all_reduce_gloo_world2(tmp_path):
+    """GradExchange (the decoder / MLP part of the flat generator gradient all-reduced from a hook inside backward, the
+    rest after it) against the single all-reduce, two gloo ranks: bitwise equal, issued before the encoder gradient is formed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "xch.py"
+    script.write_text(_XCH_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
+
+
+def test_early_exchange_ranges_cover_decoders_and_mlps():
+    """The flat-buffer ranges handed to GradExchange are exactly the decoder and MLP parameters (gen_state 1: one contiguous
+    tail of the buffer; gen_state 0: one range per generator), 16-byte aligned."""
+    from munit_amd.trainer import MUNIT_Trainer
+    for gs, n_ranges in ((1, 1), (0, 2)):
+        tr = MUNIT_Trainer(O.default_hp(64, 1, gs))
+        r = tr._early_ranges
+        assert len(r) == n_ranges and all(a % 4 == 0 and b % 4 == 0 for a, b in r), r
+        gens = [("", tr.gen)] if gs == 1 else [("a.", tr.gen_a), ("b.", tr.gen_b)]
+        names = [pre + n for pre, g in gens for n, _ in g.named_parameters()]
+        offs = tr.gen_opt._offsets
+        for n, p, off in zip(names, tr.gen_opt._plist, offs):
+            late = ".dec" in "." + n or ".mlp" in "." + n
+            inside = any(a <= off and off + p.numel() <= b for a, b in r)
+            assert inside == late, (n, off, r)
+        if gs == 1:
+            assert r[0][1] == tr.gen_opt._total
+
+
 def test_bench_self_launches_ranks_from_a_bare_shell():
     """`python bench.py --gpus 2` without a launcher must start the two ranks itself (children of a GPU-free parent),
     relay rank 0's single JSON line and return 0; --dry-run keeps it on the CPU (gloo rendezvous + all-reduce)."""

@@ -41,8 +41,20 @@ def _worker(rank, world, tmpdir):
     tr = MUNIT_Trainer(hp)
     tr.to(dev)
     batch = tuple(t.to(dev) for t in bench.make_batch(B, SIZE, rank))
+    from munit_amd import trainer as T
+    assert T.OVERLAP_EXCHANGE                       # default: decoder / MLP half of the generator gradient goes out early
     g_dis, g_gen = _step(tr, hp, batch)
     sd = {k: v.detach().cpu() for k, v in tr.gen.state_dict().items()}
+    # the same step with ONE all-reduce after backward: bitwise the same averaged gradient and weights (two ranks)
+    T.OVERLAP_EXCHANGE = False
+    torch.manual_seed(1234)
+    tr2 = MUNIT_Trainer(hp)
+    tr2.to(dev)
+    g_dis2, g_gen2 = _step(tr2, hp, batch)
+    T.OVERLAP_EXCHANGE = True
+    assert torch.equal(g_gen, g_gen2) and torch.equal(g_dis, g_dis2)
+    for (k, a), b in zip(sd.items(), tr2.gen.state_dict().values()):
+        assert torch.equal(a, b.detach().cpu()), k
     torch.save({"g_dis": g_dis, "g_gen": g_gen, "gen": sd}, os.path.join(tmpdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

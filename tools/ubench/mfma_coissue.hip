@@ -14,14 +14,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // PARTNER: 1 v_add_f32, 2 v_pk_add_f32, 3 v_fma_f32, 4 ds_write_b64 + ds_read_b64, 5 MFMA as well, 6 ds_read_b64 only
 template <int PARTNER>
-__global__ __launch_bounds__(512) void coissue(const float* a, float* out, int iters, int run_mm, int run_partner, int per_iter) {
+__global__ __launch_bounds__(512) void coissue(const float* a, float* out, int iters, int run_mm, int run_partner, int per_iter, int swap, int prio) {
   __shared__ float lds[8192];
   const int tid = threadIdx.x, wave = tid >> 6;
   const int t = blockIdx.x * blockDim.x + tid;
   float av[8];
   for (int i = 0; i < 8; ++i) av[i] = a[(t * 8 + i) & 0xFFFFF];
   float s = 0.f;
-  const bool mm = wave < 4;
+  const bool mm = swap ? wave >= 4 : wave < 4;   // swap: the matrix waves are the YOUNGER half
+  if (!mm && prio) __builtin_amdgcn_s_setprio(3);
   if ((mm && run_mm) || (!mm && run_partner && PARTNER == 5)) {
     f32x4 acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -67,13 +68,14 @@ __global__ __launch_bounds__(512) void coissue(const float* a, float* out, int i
   out[t] = s;
 }
 
+int g_swap = 0, g_prio = 0;
 template <int P>
 float run(const float* a, float* o, int iters, int mmf, int pf, int per_iter) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int l = 0; l < 2; ++l) hipLaunchKernelGGL(coissue<P>, dim3(512), dim3(512), 0, 0, a, o, iters, mmf, pf, per_iter);
+  for (int l = 0; l < 2; ++l) hipLaunchKernelGGL(coissue<P>, dim3(512), dim3(512), 0, 0, a, o, iters, mmf, pf, per_iter, g_swap, g_prio);
   hipEventRecord(e0);
-  for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(coissue<P>, dim3(512), dim3(512), 0, 0, a, o, iters, mmf, pf, per_iter);
+  for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(coissue<P>, dim3(512), dim3(512), 0, 0, a, o, iters, mmf, pf, per_iter, g_swap, g_prio);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   hipEventDestroy(e0); hipEventDestroy(e1);
@@ -91,7 +93,10 @@ int main() {
   const char* names[7] = {"", "v_add_f32", "v_pk_add_f32", "v_fma_f32", "ds_write_b64+ds_read_b64", "mfma (partner too)", "ds_read_b64"};
   // matrix waves: 2 blocks per CU in sequence x iters x 64 MFMAs x 32 cycles
   printf("ideal matrix time at 2.4 GHz: %.1f us\n", 2.0 * iters * 64 * 32 / 2400.0);
-  for (int per_iter = 64; per_iter <= 256; per_iter *= 2) {
+  for (int cfg = 0; cfg < 4; ++cfg) {
+  g_swap = cfg & 1; g_prio = cfg >> 1;
+  printf("==== matrix waves are the %s half of the block, partner at s_setprio %d\n", g_swap ? "YOUNGER (4-7)" : "OLDER (0-3)", g_prio ? 3 : 0);
+  for (int per_iter = 128; per_iter <= 128; per_iter *= 2) {
     printf("-- partner issues %d instructions per 64 MFMAs\n", per_iter);
     for (int p = 1; p <= 6; ++p) {
       float ta, tc, tb;
@@ -106,6 +111,7 @@ int main() {
       printf("%-26s matrix alone %8.1f us   partner alone %8.1f us   both %8.1f us   (max %.1f, sum %.1f)\n", names[p], ta, tc, tb,
              ta > tc ? ta : tc, ta + tc);
     }
+  }
   }
   return 0;
 }

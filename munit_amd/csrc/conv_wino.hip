@@ -226,9 +226,23 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   // half-wave's ds_read_b64 (banks mod 64) then covers 16 rows x 2 slots = 64 distinct banks; the mt term keeps the four
   // reads of a fragment set from being a constant apart, or the compiler fuses them into ds_read2st64_b64, which banks
   // mod 32 in 16-lane groups (2-way conflicts here: measured 36 % of the LDS cycles) and moves half the bytes per clock.
-  int fpos[4];
+  // The eight fragment positions (2 frequencies x 4 row tiles) are formed ONCE and made opaque to the compiler: it then
+  // cannot see that the two frequencies of a row tile are a constant apart (it would fuse the pair into ds_read2st64_b64, see
+  // above), and the loop carries no address arithmetic (the buffer offset is an immediate of the read).  Hiding the address
+  // inside the loop instead cost a v_mov + v_lshl per read: 16 vector instructions per wave and chunk, and on this chip
+  // vector instructions of either wave of a SIMD are not hidden behind v_mfma_f32_16x16x4_f32 (tools/ubench/mfma_coissue.hip).
+  // (MODE 2 -- the border fold keeps 16 more values live in the loader -- has no registers for the four extra positions: the
+  // hoisted form made the compiler shuffle registers around the transform and measured 6 % slower there, so that variant hides
+  // the address per read as before.)
+  constexpr bool HOIST = MODE != 2;
+  int fpos[2][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) fpos[mt] = mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
+  for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      fpos[fq][mt] = (HOIST ? (wave * 2 + fq) * 512 : 0) + mt * 128 + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1) ^ mt) << 1);
+      if constexpr (HOIST) asm("" : "+v"(fpos[fq][mt]));
+    }
   auto compute = [&](int buf, const UFrag& u) {
     const float* Vf = smem + buf * VBUF;
     f32x2 a[2][4];
@@ -236,9 +250,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     for (int fq = 0; fq < 2; ++fq)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        int o = (wave * 2 + fq) * 512 + fpos[mt];
-        asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
-        a[fq][mt] = *reinterpret_cast<const f32x2*>(Vf + o);
+        if constexpr (HOIST) {
+          a[fq][mt] = *reinterpret_cast<const f32x2*>(Vf + fpos[fq][mt]);
+        } else {
+          int o = (wave * 2 + fq) * 512 + fpos[0][mt];
+          asm("" : "+v"(o));   // opaque to the compiler: every fragment read stays a ds_read_b64 of its own (see above)
+          a[fq][mt] = *reinterpret_cast<const f32x2*>(Vf + o);
+        }
       }
 #pragma unroll
     for (int fq = 0; fq < 2; ++fq)
@@ -447,7 +465,15 @@ constexpr int WG_BUF = 16 * WG_PLANE;       // floats per operand buffer (32 KiB
 
 // S2: the 4x4 / stride 2 layers, F(3x3, 2x2): launch phase = parity (r, s) of the filter tap; its 2x2 gradient contracts the
 // 3x3 tiles of dy (A dY A^T with A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1]) against the 4x4 patches of input phase (r, s).
-template <bool S2>
+//
+// Round 3: a wave now loads a PAIR of tiles of ONE operand -- waves 0-3 the two input patches of tile pair (wave & 3), waves
+// 4-7 the two dy tiles -- and stores both tiles of a frequency with one ds_write_b64 ([f][tile pair][channel][2] is exactly
+// that pair).  Before, every wave loaded one tile of BOTH operands and stored 32 single dwords; per SIMD and chunk the two
+// resident waves issued ~300 vector / LDS / memory instructions next to their 128 MFMAs, now ~190 -- and on this chip those are
+// not hidden behind v_mfma_f32_16x16x4_f32 of the partner wave (tools/ubench/mfma_coissue.hip: additive), so they are what the
+// kernel's distance from the matrix roofline consists of.  FAST (host-checked: every tile of every chunk exists and every patch
+// position is inside the image after reflection) drops the per-load validity branches and the zero fills.
+template <bool S2, bool FAST>
 __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * WG_BUF];   // E0 E1 V0 V1
   const int tid = threadIdx.x, lane = tid & 63;
@@ -464,121 +490,158 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
   const unsigned xlane = (unsigned)(cib * 64 + lane) * 4u, ylane = (unsigned)(cob * 64 + lane) * 4u;
-  const bool want_db = p.db_part != nullptr && cib == 0 && (!S2 || phase == 0);
+  const bool xside = wave < 4;            // waves 0-3: input patches -> V;  waves 4-7: output-gradient tiles -> E
+  const int pair = wave & 3;              // tile pair of the chunk this wave loads (tiles 2 pair, 2 pair + 1)
+  const bool want_db_blk = p.db_part != nullptr && cib == 0 && (!S2 || phase == 0);   // block-uniform
+  const bool want_db = want_db_blk && !xside;   // the dy-side waves hold the tiles' sums
 
   constexpr int NG = S2 ? 9 : 4;   // dy values per tile
-  float d[16], g[NG];
+  // element e of every pair register = tile 2 pair + e: the loads land in the halves of a register pair, the transforms are
+  // packed adds over the pair and a frequency's two tiles leave as one ds_write_b64 -- no register shuffling in between
+  f32x2 d[16], g[NG];
   float dbs = 0.f;
-  // tile `wave` of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit)
+  // tiles 2 pair, 2 pair + 1 of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit).  The tile
+  // coordinates are carried from chunk to chunk (load_raw is called for c = 0, 1, 2, ... in order: + 8 tiles each time)
+  // instead of being divided out of the tile index every time.
+  int cur_t = c_begin * 8 + 2 * pair, cur_tx, cur_ty, cur_b;
+  {
+    const int r = cur_t / p.tw;
+    cur_tx = cur_t - r * p.tw; cur_b = r / p.th; cur_ty = r - cur_b * p.th;
+  }
   auto load_raw = [&](int c) {
-    const int t = (c_begin + c) * 8 + wave;
-    if (t < p.tiles) {
-      const int tx = t % p.tw, r = t / p.tw, ty = r % p.th, b = r / p.th;
-      int ro[4], co[4];
+    (void)c;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int ih, iw;
-        if constexpr (S2) {   // row q of input phase r = image row 2q + r - 1; the padded rows -1 and H reflect (or read 0)
-          ih = 2 * (3 * ty + i) + (phase >> 1) - 1; iw = 2 * (3 * tx + i) + (phase & 1) - 1;
-          if (p.reflect) {
-            ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
-            iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
+    for (int e = 0; e < 2; ++e) {
+      const int t = cur_t + e;
+      if (FAST || t < p.tiles) {
+        int tx = cur_tx + e, ty = cur_ty, b = cur_b;
+        if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
+        if (xside) {
+          int ro[4], co[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int ih, iw;
+            if constexpr (S2) {   // row q of input phase r = image row 2q + r - 1; the padded rows -1 and H reflect (or read 0)
+              ih = 2 * (3 * ty + i) + (phase >> 1) - 1; iw = 2 * (3 * tx + i) + (phase & 1) - 1;
+              if (p.reflect) {
+                ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
+                iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
+              }
+            } else {
+              ih = 2 * ty + p.xo + i; iw = 2 * tx + p.xo + i;
+              if (p.reflect) {
+                ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
+                iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+              }
+            }
+            if constexpr (FAST) {
+              ro[i] = (b * p.H + ih) * p.W; co[i] = iw;
+            } else {
+              ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
+              co[i] = (unsigned)iw < (unsigned)p.W ? iw : -1;
+            }
           }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (FAST || (ro[i] >= 0 && co[j] >= 0))
+                d[i * 4 + j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, xlane, (ro[i] + co[j]) * p.Cin * 4, 0));
+              else
+                d[i * 4 + j][e] = 0.f;
+            }
         } else {
-          ih = 2 * ty + p.xo + i; iw = 2 * tx + p.xo + i;
-          if (p.reflect) {
-            ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
-            iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+          const int sw = (int)p.dy_sw * 4, sh = (int)p.dy_sh * 4;
+          if constexpr (S2) {
+            const int y0 = (int)(p.dy_off + b * p.dy_sb) * 4 + 3 * ty * sh + 3 * tx * sw;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                if (FAST || (3 * ty + i < p.Ho && 3 * tx + j < p.Wo))
+                  g[i * 3 + j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + i * sh + j * sw, 0));
+                else
+                  g[i * 3 + j][e] = 0.f;
+              }
+          } else {
+            const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
+            g[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
+            g[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
+            g[2][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
+            g[3][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
           }
         }
-        ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
-        co[i] = (unsigned)iw < (unsigned)p.W ? iw : -1;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (ro[i] >= 0 && co[j] >= 0)
-            d[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, xlane, (ro[i] + co[j]) * p.Cin * 4, 0));
-          else
-            d[i * 4 + j] = 0.f;
-        }
-      const int sw = (int)p.dy_sw * 4, sh = (int)p.dy_sh * 4;
-      if constexpr (S2) {
-        const int y0 = (int)(p.dy_off + b * p.dy_sb) * 4 + 3 * ty * sh + 3 * tx * sw;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            if (3 * ty + i < p.Ho && 3 * tx + j < p.Wo)
-              g[i * 3 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + i * sh + j * sw, 0));
-            else
-              g[i * 3 + j] = 0.f;
-          }
       } else {
-        const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
-        g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
-        g[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
-        g[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
-        g[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) g[q][e] = 0.f;
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) d[q] = 0.f;
-#pragma unroll
-      for (int q = 0; q < NG; ++q) g[q] = 0.f;
     }
+    cur_t += 8; cur_tx += 8;
+    while (cur_tx >= p.tw) { cur_tx -= p.tw; if (++cur_ty >= p.th) { cur_ty = 0; ++cur_b; } }
   };
-  // plane position of (tile pair kq = wave >> 1, channel lane, element wave & 1); odd pairs swap the two 16-channel
+  // plane position of (tile pair `pair`, channel lane): one b64 = the pair's two tiles; odd pairs swap the two 16-channel
   // halves of every 32 so that the half-wave fragment reads below (pairs {0,1} or {2,3}) cover all 64 banks
-  const int wpos = ((wave >> 1) * 64 + (lane ^ (((wave >> 1) & 1) << 4))) * 2 + (wave & 1);
+  const int wpos = (pair * 64 + (lane ^ ((pair & 1) << 4))) * 2;
   auto transform_store = [&](int buf) {
-    float* E = smem + buf * WG_BUF + wpos;
-    float* V = smem + (2 + buf) * WG_BUF + wpos;
-    if constexpr (S2) {
-      if (want_db) dbs += ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + g[8];
-      // E = A dY A^T, A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1]
-      float r[4][3];
+    if (xside) {
+      float* V = smem + (2 + buf) * WG_BUF + wpos;
+      f32x2 u[16];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        r[0][j] = g[j];
-        r[1][j] = (g[j] + g[6 + j]) + g[3 + j];
-        r[2][j] = (g[j] + g[6 + j]) - g[3 + j];
-        r[3][j] = -g[6 + j];
+      for (int j = 0; j < 4; ++j) {   // B^T d
+        u[0 + j] = d[0 + j] - d[8 + j];
+        u[4 + j] = d[4 + j] + d[8 + j];
+        u[8 + j] = d[8 + j] - d[4 + j];
+        u[12 + j] = d[4 + j] - d[12 + j];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        E[(i * 4 + 0) * WG_PLANE] = r[i][0];
-        E[(i * 4 + 1) * WG_PLANE] = (r[i][0] + r[i][2]) + r[i][1];
-        E[(i * 4 + 2) * WG_PLANE] = (r[i][0] + r[i][2]) - r[i][1];
-        E[(i * 4 + 3) * WG_PLANE] = -r[i][2];
+      for (int i = 0; i < 4; ++i) {   // (.) B
+        *reinterpret_cast<f32x2*>(V + (i * 4 + 0) * WG_PLANE) = u[i * 4 + 0] - u[i * 4 + 2];
+        *reinterpret_cast<f32x2*>(V + (i * 4 + 1) * WG_PLANE) = u[i * 4 + 1] + u[i * 4 + 2];
+        *reinterpret_cast<f32x2*>(V + (i * 4 + 2) * WG_PLANE) = u[i * 4 + 2] - u[i * 4 + 1];
+        *reinterpret_cast<f32x2*>(V + (i * 4 + 3) * WG_PLANE) = u[i * 4 + 1] - u[i * 4 + 3];
       }
     } else {
-      if (want_db) dbs += (g[0] + g[1]) + (g[2] + g[3]);
-      // E = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
-      const float r[4][2] = {{g[0], g[1]}, {g[0] + g[2], g[1] + g[3]}, {g[0] - g[2], g[1] - g[3]}, {-g[2], -g[3]}};
+      float* E = smem + buf * WG_BUF + wpos;
+      if constexpr (S2) {
+        if (want_db) {
+          const f32x2 sum = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + g[8];
+          dbs += sum[0];
+          dbs += sum[1];
+        }
+        // E = A dY A^T, A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1]
+        f32x2 r[4][3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        E[(i * 4 + 0) * WG_PLANE] = r[i][0];
-        E[(i * 4 + 1) * WG_PLANE] = r[i][0] + r[i][1];
-        E[(i * 4 + 2) * WG_PLANE] = r[i][0] - r[i][1];
-        E[(i * 4 + 3) * WG_PLANE] = -r[i][1];
+        for (int j = 0; j < 3; ++j) {
+          r[0][j] = g[j];
+          r[1][j] = (g[j] + g[6 + j]) + g[3 + j];
+          r[2][j] = (g[j] + g[6 + j]) - g[3 + j];
+          r[3][j] = -g[6 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 0) * WG_PLANE) = r[i][0];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 1) * WG_PLANE) = (r[i][0] + r[i][2]) + r[i][1];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 2) * WG_PLANE) = (r[i][0] + r[i][2]) - r[i][1];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 3) * WG_PLANE) = -r[i][2];
+        }
+      } else {
+        if (want_db) {
+          const f32x2 sum = (g[0] + g[1]) + (g[2] + g[3]);
+          dbs += sum[0];
+          dbs += sum[1];
+        }
+        // E = A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+        const f32x2 r[4][2] = {{g[0], g[1]}, {g[0] + g[2], g[1] + g[3]}, {g[0] - g[2], g[1] - g[3]}, {-g[2], -g[3]}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 0) * WG_PLANE) = r[i][0];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 1) * WG_PLANE) = r[i][0] + r[i][1];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 2) * WG_PLANE) = r[i][0] - r[i][1];
+          *reinterpret_cast<f32x2*>(E + (i * 4 + 3) * WG_PLANE) = -r[i][1];
+        }
       }
-    }
-    float u[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // B^T d
-      u[0 + j] = d[0 + j] - d[8 + j];
-      u[4 + j] = d[4 + j] + d[8 + j];
-      u[8 + j] = d[8 + j] - d[4 + j];
-      u[12 + j] = d[4 + j] - d[12 + j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // (.) B
-      V[(i * 4 + 0) * WG_PLANE] = u[i * 4 + 0] - u[i * 4 + 2];
-      V[(i * 4 + 1) * WG_PLANE] = u[i * 4 + 1] + u[i * 4 + 2];
-      V[(i * 4 + 2) * WG_PLANE] = u[i * 4 + 2] - u[i * 4 + 1];
-      V[(i * 4 + 3) * WG_PLANE] = u[i * 4 + 1] - u[i * 4 + 3];
     }
   };
 
@@ -589,26 +652,24 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[fq][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragment: channel row r = lane & 15 of 16-channel tile mt, tile pair kq = lane >> 4
-  int fpos[4];
+  // fragment: channel row r = lane & 15 of 16-channel tile mt, tile pair kq = lane >> 4.  Positions formed once and made
+  // opaque (see the forward kernel): no address arithmetic in the loop, and the reads of the two frequencies are not fused
+  int fpos[2][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) fpos[mt] = ((lane >> 4) * 64 + ((mt * 16 + (lane & 15)) ^ (((lane >> 4) & 1) << 4))) * 2;
+  for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      fpos[fq][mt] = (wave * 2 + fq) * WG_PLANE + ((lane >> 4) * 64 + ((mt * 16 + (lane & 15)) ^ (((lane >> 4) & 1) << 4))) * 2;
+      asm("" : "+v"(fpos[fq][mt]));
+    }
   auto compute = [&](int buf, int fq) {
     const float* Ef = smem + buf * WG_BUF;
     const float* Vf = smem + (2 + buf) * WG_BUF;
     f32x2 a[4], bb[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      int o = (wave * 2 + fq) * WG_PLANE + fpos[nt];
-      asm("" : "+v"(o));   // keeps every fragment read a ds_read_b64 of its own (see the forward kernel)
-      bb[nt] = *reinterpret_cast<const f32x2*>(Vf + o);
-    }
+    for (int nt = 0; nt < 4; ++nt) bb[nt] = *reinterpret_cast<const f32x2*>(Vf + fpos[fq][nt]);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      int o = (wave * 2 + fq) * WG_PLANE + fpos[mt];
-      asm("" : "+v"(o));
-      a[mt] = *reinterpret_cast<const f32x2*>(Ef + o);
-    }
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x2*>(Ef + fpos[fq][mt]);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -652,7 +713,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
         for (int r = 0; r < 4; ++r)
           sl[((long long)(wave * 2 + fq) * p.Cout + cob * 64 + mt * 16 + 4 * (lane >> 4) + r) * p.Cin + cib * 64 + nt * 16 + (lane & 15)] =
               acc[fq][mt][nt][r];
-  if (want_db) {   // bias: the 8 waves hold the sums of their tiles for channel `lane`
+  if (want_db_blk) {   // bias: the dy-side waves hold the sums of their tiles for channel `lane` (the others 0)
     smem[wave * 64 + lane] = dbs;
     __syncthreads();
     if (wave == 0) {
@@ -771,8 +832,18 @@ int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, fl
                                             align_up((size_t)p.ksplit * p.phases * 16 * p.Cin * p.Cout * sizeof(float), 256));
   p.db_part = db != nullptr ? db_part : nullptr;
   const dim3 grid((unsigned)(p.CB * p.NB * p.ksplit), (unsigned)p.phases);
-  if (p.s2) hipLaunchKernelGGL(conv_wino_wgrad_kernel<true>, grid, dim3(512), 0, st, p);
-  else hipLaunchKernelGGL(conv_wino_wgrad_kernel<false>, grid, dim3(512), 0, st, p);
+  // FAST: every tile of every chunk exists and every patch / dy position lies inside its tensor (after reflection)
+  bool fast = p.tiles % 8 == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINO_WGRAD_FAST");
+  if (p.s2) fast = fast && p.reflect && p.H % 6 == 0 && p.W % 6 == 0 && p.Ho % 3 == 0 && p.Wo % 3 == 0;
+  else fast = fast && (p.xo == -1 ? (p.reflect && p.H >= 2 && p.W >= 2 && 2 * p.th <= p.H && 2 * p.tw <= p.W)
+                                  : (p.xo >= 0 && 2 * (p.th - 1) + p.xo + 3 < p.H && 2 * (p.tw - 1) + p.xo + 3 < p.W));
+  if (p.s2) {
+    if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, false>), grid, dim3(512), 0, st, p);
+  } else {
+    if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, false>), grid, dim3(512), 0, st, p);
+  }
   MUNIT_CHECK_LAUNCH("conv_wino_wgrad");
   const int pair_blocks = cdiv((long long)p.Cout * p.Cin, 256);
   const int bias_blocks = db != nullptr ? cdiv(p.Cout, 256) : 0;

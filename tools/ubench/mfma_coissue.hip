@@ -12,7 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-// PARTNER: 1 v_add_f32, 2 v_pk_add_f32, 3 v_fma_f32, 4 ds_write_b64 + ds_read_b64, 5 MFMA as well, 6 ds_read_b64 only
+// PARTNER: 1 v_add_f32, 2 v_pk_add_f32, 3 v_fma_f32, 4 ds_write_b64 + ds_read_b64, 5 MFMA as well, 6 ds_read_b64 only,
+// 7 scalar ALU (s_add / s_mul), 8 global_load_dword (L2 hits, 8 in flight)
 template <int PARTNER>
 __global__ __launch_bounds__(512) void coissue(const float* a, float* out, int iters, int run_mm, int run_partner, int per_iter, int swap, int prio) {
   __shared__ float lds[8192];
@@ -52,6 +53,23 @@ __global__ __launch_bounds__(512) void coissue(const float* a, float* out, int i
         asm volatile("v_fma_f32 %0, %0, %4, %1\n v_fma_f32 %1, %1, %5, %2\n v_fma_f32 %2, %2, %6, %3\n v_fma_f32 %3, %3, %7, %0\n"
                      "v_fma_f32 %4, %4, %0, %5\n v_fma_f32 %5, %5, %1, %6\n v_fma_f32 %6, %6, %2, %7\n v_fma_f32 %7, %7, %3, %4\n"
                      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+    } else if constexpr (PARTNER == 7) {      // scalar ALU: wave-uniform address arithmetic
+      int s0 = __builtin_amdgcn_readfirstlane(tid), s1 = 3, s2 = 5, s3 = 7;
+      for (int i = 0; i < n; ++i)
+        asm volatile("s_add_i32 %0, %0, %1\n s_mul_i32 %1, %1, %2\n s_add_i32 %2, %2, %3\n s_sub_i32 %3, %3, %0\n"
+                     "s_add_i32 %0, %0, %2\n s_mul_i32 %1, %1, %3\n s_add_i32 %2, %2, %0\n s_sub_i32 %3, %3, %1\n"
+                     : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));
+      r0 += (float)(s0 + s1 + s2 + s3);
+    } else if constexpr (PARTNER == 8) {      // vector memory: L2-resident dword loads, 8 in flight
+      const float* q = a + (tid & 255);
+      for (int i = 0; i < n; ++i) {
+        float t0, t1, t2, t3, t4, t5, t6, t7;
+        asm volatile("global_load_dword %0, %8, off\n global_load_dword %1, %8, off offset:1024\n global_load_dword %2, %8, off offset:2048\n"
+                     "global_load_dword %3, %8, off offset:3072\n global_load_dword %4, %8, off offset:64\n global_load_dword %5, %8, off offset:1088\n"
+                     "global_load_dword %6, %8, off offset:2112\n global_load_dword %7, %8, off offset:3136\n s_waitcnt vmcnt(0)\n"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(q) : "memory");
+        r0 += t0 + t1 + t2 + t3 + t4 + t5 + t6 + t7;
+      }
     } else if constexpr (PARTNER == 4 || PARTNER == 6) {
       float* q = lds + (tid & 255) * 2;
       for (int i = 0; i < n; ++i) {
@@ -90,15 +108,15 @@ int main() {
   float *a, *o;
   CK(hipMalloc(&a, N * 4)); CK(hipMalloc(&o, 512 * 512 * 4));
   CK(hipMemcpy(a, h.data(), N * 4, hipMemcpyHostToDevice));
-  const char* names[7] = {"", "v_add_f32", "v_pk_add_f32", "v_fma_f32", "ds_write_b64+ds_read_b64", "mfma (partner too)", "ds_read_b64"};
+  const char* names[9] = {"", "v_add_f32", "v_pk_add_f32", "v_fma_f32", "ds_write_b64+ds_read_b64", "mfma (partner too)", "ds_read_b64", "s_add/s_mul (SALU)", "global_load_dword x8"};
   // matrix waves: 2 blocks per CU in sequence x iters x 64 MFMAs x 32 cycles
   printf("ideal matrix time at 2.4 GHz: %.1f us\n", 2.0 * iters * 64 * 32 / 2400.0);
-  for (int cfg = 0; cfg < 4; ++cfg) {
+  for (int cfg = 0; cfg < 1; ++cfg) {
   g_swap = cfg & 1; g_prio = cfg >> 1;
   printf("==== matrix waves are the %s half of the block, partner at s_setprio %d\n", g_swap ? "YOUNGER (4-7)" : "OLDER (0-3)", g_prio ? 3 : 0);
   for (int per_iter = 128; per_iter <= 128; per_iter *= 2) {
     printf("-- partner issues %d instructions per 64 MFMAs\n", per_iter);
-    for (int p = 1; p <= 6; ++p) {
+    for (int p = 1; p <= 8; ++p) {
       float ta, tc, tb;
       switch (p) {
         case 1: ta = run<1>(a, o, iters, 1, 0, per_iter); tc = run<1>(a, o, iters, 0, 1, per_iter); tb = run<1>(a, o, iters, 1, 1, per_iter); break;
@@ -106,6 +124,8 @@ int main() {
         case 3: ta = run<3>(a, o, iters, 1, 0, per_iter); tc = run<3>(a, o, iters, 0, 1, per_iter); tb = run<3>(a, o, iters, 1, 1, per_iter); break;
         case 4: ta = run<4>(a, o, iters, 1, 0, per_iter); tc = run<4>(a, o, iters, 0, 1, per_iter); tb = run<4>(a, o, iters, 1, 1, per_iter); break;
         case 5: ta = run<5>(a, o, iters, 1, 0, per_iter); tc = run<5>(a, o, iters, 0, 1, per_iter); tb = run<5>(a, o, iters, 1, 1, per_iter); break;
+        case 7: ta = run<7>(a, o, iters, 1, 0, per_iter); tc = run<7>(a, o, iters, 0, 1, per_iter); tb = run<7>(a, o, iters, 1, 1, per_iter); break;
+        case 8: ta = run<8>(a, o, iters, 1, 0, per_iter); tc = run<8>(a, o, iters, 0, 1, per_iter); tb = run<8>(a, o, iters, 1, 1, per_iter); break;
         default: ta = run<6>(a, o, iters, 1, 0, per_iter); tc = run<6>(a, o, iters, 0, 1, per_iter); tb = run<6>(a, o, iters, 1, 1, per_iter); break;
       }
       printf("%-26s matrix alone %8.1f us   partner alone %8.1f us   both %8.1f us   (max %.1f, sum %.1f)\n", names[p], ta, tc, tb,

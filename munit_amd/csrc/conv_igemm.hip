@@ -1630,15 +1630,8 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
     q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 2 : 1;
     q.th = d->H / 2; q.tw = d->W / 2; q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cin / 64;
     q.act = MUNIT_ACT_NONE; q.slope = 0.f;
-    rc = munit_wino_launch(q, st);
-    if (rc) return rc;
-    if (add != nullptr) {
-      long long n = (long long)d->B * d->H * d->W * d->Cin;
-      int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
-      hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, dx, add, n);
-      MUNIT_CHECK_LAUNCH("add_inplace");
-    }
-    return MUNIT_OK;
+    q.add = add;    // added in the kernel's epilogue (dx and add share the layout)
+    return munit_wino_launch(q, st);
   }
   {
     // data gradient of a 7x7 conv with 3 input channels (first encoder layers): the padded-domain

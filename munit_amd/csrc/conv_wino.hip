@@ -435,12 +435,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           s[4 + j] = (m[4 + j] - m[8 + j]) - m[12 + j];
         }
         if (ty < p.th && tx < p.tw) {
-          float* yp = p.y + (phase >> 1) * p.y_prow + (phase & 1) * p.y_pcol + b * p.y_sb + (long long)(2 * ty) * p.y_sh +
-                      (long long)(2 * tx) * p.y_sw + n;
-          yp[0] = wino_act(((s[0] + s[1]) + s[2]) + bv, p.act, slope);
-          yp[p.y_sw] = wino_act(((s[1] - s[2]) - s[3]) + bv, p.act, slope);
-          yp[p.y_sh] = wino_act(((s[4] + s[5]) + s[6]) + bv, p.act, slope);
-          yp[p.y_sh + p.y_sw] = wino_act(((s[5] - s[6]) - s[7]) + bv, p.act, slope);
+          const long long yo = (phase >> 1) * p.y_prow + (phase & 1) * p.y_pcol + b * p.y_sb + (long long)(2 * ty) * p.y_sh +
+                               (long long)(2 * tx) * p.y_sw + n;
+          float* yp = p.y + yo;
+          float v0 = ((s[0] + s[1]) + s[2]) + bv, v1 = ((s[1] - s[2]) - s[3]) + bv;
+          float v2 = ((s[4] + s[5]) + s[6]) + bv, v3 = ((s[5] - s[6]) - s[7]) + bv;
+          if (p.add != nullptr) {   // backward-data of the first conv of a ResBlock: + the gradient of the skip connection
+            const float* ap = p.add + yo;
+            v0 += ap[0]; v1 += ap[p.y_sw]; v2 += ap[p.y_sh]; v3 += ap[p.y_sh + p.y_sw];
+          }
+          yp[0] = wino_act(v0, p.act, slope);
+          yp[p.y_sw] = wino_act(v1, p.act, slope);
+          yp[p.y_sh] = wino_act(v2, p.act, slope);
+          yp[p.y_sh + p.y_sw] = wino_act(v3, p.act, slope);
         }
       }
     }

@@ -167,6 +167,7 @@ struct WinoParams {
   const float* x;      // NHWC input [B][H][W][K]
   const float* u;      // transformed weights (see above)
   const float* bias;   // [N] or null
+  const float* add;    // null, or a tensor laid out like y that the epilogue adds (3x3 layers: the ResBlock skip gradient)
   float* y;            // output pixel (b, oh, ow) channel n at y[b*y_sb + oh*y_sh + ow*y_sw + n]
   long long y_sb, y_sh, y_sw;
   // gridDim.y launch phases (sub-pixel up-sampling conv: 4): phase ph = 2a + b reads u + ph * u_phase and writes to

@@ -43,8 +43,8 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2, out_dtype=None):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, pad, pad_type, upsample, act, slope, out_dtype)
+    def forward(self, x, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2, out_dtype=None, link=None):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, pad, pad_type, upsample, act, slope, out_dtype, link)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size,
@@ -77,8 +77,8 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.num_features, self.eps = num_features, eps
 
-    def forward(self, x, relu=False, residual=None):
-        return ops.instance_norm(x, relu, residual, self.eps)
+    def forward(self, x, relu=False, residual=None, link=None):
+        return ops.instance_norm(x, relu, residual, self.eps, link)
 
 
 class AdaptiveInstanceNorm2d(nn.Module):
@@ -94,17 +94,18 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
 
-    def forward(self, x, relu=False, residual=None):
+    def forward(self, x, relu=False, residual=None, link=None):
         assert self.weight is not None and self.bias is not None, \
             "Please assign weight and bias before calling AdaIN!"
+        sink, first = None, False
         if self._params is not None:
-            params, w_off, b_off = self._params
+            params, w_off, b_off, sink, first = self._params
         else:
             # weight / bias assigned by hand as flat (B*C,) tensors (reference convention)
             b, c = x.size(0), x.size(1)
             params = torch.cat([self.bias.reshape(b, c), self.weight.reshape(b, c)], dim=1).contiguous()
             w_off, b_off = c, 0
-        return ops.adain(x, params, w_off, b_off, relu, residual, self.eps)
+        return ops.adain(x, params, w_off, b_off, relu, residual, self.eps, link, sink, first)
 
     def __repr__(self):
         return self.__class__.__name__ + "(" + str(self.num_features) + ")"
@@ -182,18 +183,20 @@ class Conv2dBlock(nn.Module):
         self.activation = activation
         self.conv = Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)
 
-    def forward(self, x, upsample=False, residual=None, out_dtype=None):
+    def forward(self, x, upsample=False, residual=None, out_dtype=None, link_open=None, link_close=None):
+        """link_open / link_close: the ops.ResidualLink of the ResBlock this block opens (its convolution's backward-data
+        adds the skip gradient) / closes (its norm's backward parks the skip gradient instead of returning it)."""
         if self.norm is None:
-            y = self.conv(x, self.pad.padding, self.pad.kind, upsample, self.activation, out_dtype=out_dtype)
+            y = self.conv(x, self.pad.padding, self.pad.kind, upsample, self.activation, out_dtype=out_dtype, link=link_open)
             if residual is not None:
                 raise NotImplementedError("munit_amd: residual add needs a normalised block")
             return y
-        y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none", out_dtype=out_dtype)
+        y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none", out_dtype=out_dtype, link=link_open)
         relu = self.activation == "relu"
         if isinstance(self.norm, LayerNorm):
             assert residual is None
             return self.norm(y, relu)
-        return self.norm(y, relu, residual)
+        return self.norm(y, relu, residual, link_close)
 
 
 class ResBlock(nn.Module):
@@ -206,7 +209,11 @@ class ResBlock(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, x):
-        return self.model[1](self.model[0](x), residual=x)
+        # x feeds the first convolution and the skip connection; in backward the two gradients meet inside that convolution's
+        # backward-data (ops.ResidualLink) instead of in a separate element-wise add
+        link = ops.ResidualLink() if (torch.is_grad_enabled() and x.requires_grad and ops.FUSE_SKIP_GRAD) else None
+        h = self.model[0](x, link_open=link)
+        return self.model[1](h, residual=x, link_close=link)
 
 
 class ResBlocks(nn.Module):
@@ -348,15 +355,20 @@ def _assign_adain_params(adain_params, model):
     if adain_params.dim() != 2:
         adain_params = adain_params.reshape(adain_params.size(0), -1)
     adain_params = adain_params.contiguous()
+    layers = [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"]
+    # When the layers' column ranges tile the tensor exactly (the shipped geometry: the MLP emits get_num_adain_params
+    # columns), their backward passes write their slices of ONE gradient buffer and the first layer hands it to autograd
+    # (ops.AdainGradSink) -- instead of eight zero-filled (B, n) tensors summed by seven element-wise kernels per decode.
+    exact = sum(2 * m.num_features for m in layers) == adain_params.size(1)
+    sink = ops.AdainGradSink() if (exact and torch.is_grad_enabled() and adain_params.requires_grad and ops.FUSE_ADAIN_GRAD) else None
     off = 0
-    for m in model.modules():
-        if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
-            c = m.num_features
-            m._params = (adain_params, off + c, off)
-            m.bias = adain_params.detach()[:, off:off + c]
-            m.weight = adain_params.detach()[:, off + c:off + 2 * c]
-            if adain_params.size(1) > off + 2 * c:
-                off += 2 * c
+    for i, m in enumerate(layers):
+        c = m.num_features
+        m._params = (adain_params, off + c, off, sink, i == 0)
+        m.bias = adain_params.detach()[:, off:off + c]
+        m.weight = adain_params.detach()[:, off + c:off + 2 * c]
+        if adain_params.size(1) > off + 2 * c:
+            off += 2 * c
 
 
 def _num_adain_params(model):

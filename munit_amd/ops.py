@@ -404,9 +404,47 @@ def join_side_streams():
         stream_wait(torch.cuda.current_stream(torch.device("cuda", index)), st)
 
 
+FUSE_SKIP_GRAD = not os.environ.get("MUNIT_NO_FUSE_SKIP_GRAD")   # A/B switch of ResidualLink
+
+
+class ResidualLink(object):
+    """Carries the gradient of a ResBlock's skip connection (networks.py:620-623, `out += residual`) from the block's last
+    norm -- whose backward receives it -- to the block's FIRST convolution, whose backward-data adds it to dx in its epilogue
+    (munit_conv2d_dgrad's `add` operand).  Autograd would otherwise sum the two gradients of the block input with a separate
+    element-wise kernel over a 33 MB tensor per block (40 per gen_update).  One link per block call; the norm's backward runs
+    first (it is the last node of the block), the convolution's last, both on the stream the block was recorded on."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+    def park(self, dy):
+        if self.grad is not None:
+            raise RuntimeError("munit_amd: ResidualLink used twice in one backward pass")
+        self.grad = dy
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+FUSE_ADAIN_GRAD = not os.environ.get("MUNIT_NO_FUSE_ADAIN_GRAD")   # A/B switch of AdainGradSink
+
+
+class AdainGradSink(object):
+    """One gradient buffer for the (B, n) AdaIN parameter tensor of a decode call (networks.py:230-239 slices it into the
+    eight layers' weight / bias columns).  Every layer's backward writes its own columns in place; the FIRST layer of the
+    module order -- whose backward runs last, all later layers being downstream of it -- returns the buffer to autograd, the
+    others return nothing.  Replaces eight zero-filled (B, n) gradients summed by seven element-wise kernels."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf, owner, out_dtype):
+    def forward(ctx, x, weight, bias, stride, pad, pad_type, upsample, act, slope, wbuf, bbuf, owner, out_dtype, link=None):
         _require(x, "conv input", bf16_ok=True)
         _require(weight, "conv weight")
         x, w = nhwc(x), nhwc(weight)
@@ -418,6 +456,7 @@ class _Conv2d(Function):
         ctx.wbuf = wbuf
         ctx.bbuf = bbuf if bias is not None else None
         ctx.owner = owner
+        ctx.link = link
         ctx.save_for_backward(x, w, y if act != "none" else None)
         return y
 
@@ -444,10 +483,11 @@ class _Conv2d(Function):
                 conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, dw=ctx.wbuf, db=ctx.bbuf, beta=1.0,
                                  want_bias=False)
         if ctx.needs_input_grad[0]:
-            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample, owner=ctx.owner, x_dtype=x.dtype)
+            skip = ctx.link.take() if ctx.link is not None else None      # gradient of the ResBlock skip connection
+            dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, pad_type, upsample, add=skip, owner=ctx.owner, x_dtype=x.dtype)
         if want_w and ctx.wbuf is None:
             dw, db = conv2d_wgrad_raw(x, dy, w.shape, stride, pad, pad_type, upsample, want_bias=ctx.has_bias)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _gbuf(p):
@@ -455,11 +495,12 @@ def _gbuf(p):
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_type="zero", upsample=False, act="none", slope=0.2,
-           out_dtype=None):
+           out_dtype=None, link=None):
     """pad -> conv -> bias -> activation (networks.py:695-701), optional fused nearest x2
-    upsample of the input (networks.py:534).  out_dtype: see conv2d_fwd_raw."""
+    upsample of the input (networks.py:534).  out_dtype: see conv2d_fwd_raw.  link: ResidualLink of the ResBlock this
+    convolution opens (its backward-data then adds the skip gradient parked there)."""
     return _Conv2d.apply(x, weight, bias, stride, pad, pad_type, upsample, act, slope, _gbuf(weight), _gbuf(bias),
-                         weight, out_dtype)
+                         weight, out_dtype, link)
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -477,7 +518,7 @@ def linear(x, weight, bias=None, act="none"):
 class _InstNorm(Function):
     @staticmethod
     @_guarded
-    def forward(ctx, x, adain, residual, w_off, b_off, relu, eps):
+    def forward(ctx, x, adain, residual, w_off, b_off, relu, eps, link=None, sink=None, sink_first=False):
         _require(x, "instance-norm input", bf16_ok=True)
         lib = _lib.load()
         x = nhwc(x)
@@ -500,6 +541,8 @@ class _InstNorm(Function):
                       c_float(eps), _p(ws), ws.numel(), _stream()), "instnorm_fwd")
         ctx.cfg = (w_off, b_off, relu, ld)
         ctx.has_res = residual is not None
+        ctx.link = link if residual is not None else None
+        ctx.sink, ctx.sink_first = (sink, sink_first) if adain is not None else (None, False)
         ctx.save_for_backward(x, stats, adain)
         if MASK_SINK is not None and relu:
             if residual is not None:
@@ -517,7 +560,12 @@ class _InstNorm(Function):
         b, c, h, w = x.shape
         dx = torch.empty_like(x)
         d_adain = None
-        if adain is not None and ctx.needs_input_grad[1]:
+        sink = ctx.sink if (adain is not None and ctx.needs_input_grad[1]) else None
+        if sink is not None:
+            if sink.buf is None:                     # the last AdaIN layer's backward comes first
+                sink.buf = torch.empty_like(adain)   # every column is written by exactly one layer (checked at assignment)
+            d_adain = sink.buf
+        elif adain is not None and ctx.needs_input_grad[1]:
             d_adain = torch.zeros_like(adain)
         ws = workspace(lib.munit_instnorm_workspace_bytes(b, h * w, c), x.device)
         if dy.dtype != x.dtype:
@@ -525,18 +573,26 @@ class _InstNorm(Function):
         fn = lib.munit_instnorm_bwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_instnorm_bwd
         _lib.check(fn(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(adain), _p(d_adain), ld, w_off, b_off,
                       int(relu), _p(ws), ws.numel(), _stream()), "instnorm_bwd")
-        return dx, d_adain, (dy if ctx.has_res else None), None, None, None, None
+        if sink is not None:
+            if ctx.sink_first:
+                sink.buf = None                      # handed to autograd: the buffer is complete
+            else:
+                d_adain = None
+        if ctx.link is not None:        # the block's first convolution adds the skip gradient inside its backward-data
+            ctx.link.park(dy)
+            return dx, d_adain, None, None, None, None, None, None, None, None
+        return dx, d_adain, (dy if ctx.has_res else None), None, None, None, None, None, None, None
 
 
-def instance_norm(x, relu=False, residual=None, eps=1e-5):
-    """nn.InstanceNorm2d(affine=False) (networks.py:657) [+ReLU] [+residual]."""
-    return _InstNorm.apply(x, None, residual, 0, 0, relu, eps)
+def instance_norm(x, relu=False, residual=None, eps=1e-5, link=None):
+    """nn.InstanceNorm2d(affine=False) (networks.py:657) [+ReLU] [+residual].  link: see ResidualLink."""
+    return _InstNorm.apply(x, None, residual, 0, 0, relu, eps, link)
 
 
-def adain(x, params, w_off, b_off, relu=False, residual=None, eps=1e-5):
+def adain(x, params, w_off, b_off, relu=False, residual=None, eps=1e-5, link=None, sink=None, sink_first=False):
     """AdaptiveInstanceNorm2d (networks.py:823-845); weight/bias are columns
-    [w_off, w_off+C) / [b_off, b_off+C) of the (B, n) MLP output."""
-    return _InstNorm.apply(x, params, residual, w_off, b_off, relu, eps)
+    [w_off, w_off+C) / [b_off, b_off+C) of the (B, n) MLP output.  sink / sink_first: see AdainGradSink."""
+    return _InstNorm.apply(x, params, residual, w_off, b_off, relu, eps, link, sink, sink_first)
 
 
 class _LayerNorm(Function):

@@ -485,7 +485,14 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   __shared__ __attribute__((aligned(16))) float smem[4 * WG_BUF];   // E0 E1 V0 V1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order (blocks b and b + 8 share an XCD and its L2): every XCD gets one contiguous run of block indices, so the
+  // CB x NB blocks of a tile-range split -- which read the same x tiles (NB times) and the same dy tiles (CB times) -- meet in
+  // one L2 instead of fetching them through eight
   int blk = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blk & 7, idx = blk >> 3;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int cib = blk % p.CB; blk /= p.CB;
   const int cob = blk % p.NB;
   const int split = blk / p.NB;

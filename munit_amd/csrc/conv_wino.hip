@@ -26,6 +26,7 @@
 //     them into the 2x2 pixels, adds bias, applies the activation and stores 128-byte row segments.
 #include "wino.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -514,22 +515,11 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   // packed adds over the pair and a frequency's two tiles leave as one ds_write_b64 -- no register shuffling in between
   f32x2 d[16], g[NG];
   float dbs = 0.f;
-  // tiles 2 pair, 2 pair + 1 of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit).  The tile
-  // coordinates are carried from chunk to chunk (load_raw is called for c = 0, 1, 2, ... in order: + 8 tiles each time)
-  // instead of being divided out of the tile index every time.
-  int cur_t = c_begin * 8 + 2 * pair, cur_tx, cur_ty, cur_b;
-  {
-    const int r = cur_t / p.tw;
-    cur_tx = cur_t - r * p.tw; cur_b = r / p.th; cur_ty = r - cur_b * p.th;
-  }
-  auto load_raw = [&](int c) {
-    (void)c;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int t = cur_t + e;
-      if (FAST || t < p.tiles) {
-        int tx = cur_tx + e, ty = cur_ty, b = cur_b;
-        if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
+  // one tile of this wave's operand into element e of the pair registers.  INNER (wave-uniform, decided per tile): the whole
+  // patch / dy tile lies inside its tensor after reflection, so no position needs a validity test -- true for every tile when
+  // FAST, else for all but the ragged last tile row / column (and zero-padded borders)
+  auto load_tile_impl = [&](auto inner_tag, int e, int tx, int ty, int b) {
+    constexpr bool INNER = decltype(inner_tag)::value;
         if (xside) {
           int ro[4], co[4];
 #pragma unroll
@@ -548,7 +538,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
                 iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
               }
             }
-            if constexpr (FAST) {
+            if constexpr (INNER) {
               ro[i] = (b * p.H + ih) * p.W; co[i] = iw;
             } else {
               ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
@@ -559,7 +549,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              if (FAST || (ro[i] >= 0 && co[j] >= 0))
+              if (INNER || (ro[i] >= 0 && co[j] >= 0))
                 d[i * 4 + j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, xlane, (ro[i] + co[j]) * p.Cin * 4, 0));
               else
                 d[i * 4 + j][e] = 0.f;
@@ -572,7 +562,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
             for (int i = 0; i < 3; ++i)
 #pragma unroll
               for (int j = 0; j < 3; ++j) {
-                if (FAST || (3 * ty + i < p.Ho && 3 * tx + j < p.Wo))
+                if (INNER || (3 * ty + i < p.Ho && 3 * tx + j < p.Wo))
                   g[i * 3 + j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + i * sh + j * sw, 0));
                 else
                   g[i * 3 + j][e] = 0.f;
@@ -585,6 +575,33 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
             g[3][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
           }
         }
+  };
+  auto load_tile = [&](int e, int tx, int ty, int b) {
+    bool inner = FAST;
+    if constexpr (!FAST) {
+      if constexpr (S2) inner = p.reflect && 6 * ty + 6 <= p.H && 6 * tx + 6 <= p.W && 3 * ty + 2 < p.Ho && 3 * tx + 2 < p.Wo;
+      else inner = p.xo == -1 ? (p.reflect != 0) : (2 * ty + p.xo + 3 < p.H && 2 * tx + p.xo + 3 < p.W && p.xo >= 0);
+    }
+    if (inner) load_tile_impl(std::true_type{}, e, tx, ty, b);
+    else load_tile_impl(std::false_type{}, e, tx, ty, b);
+  };
+  // tiles 2 pair, 2 pair + 1 of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit).  The tile
+  // coordinates are carried from chunk to chunk (load_raw is called for c = 0, 1, 2, ... in order: + 8 tiles each time)
+  // instead of being divided out of the tile index every time.
+  int cur_t = c_begin * 8 + 2 * pair, cur_tx, cur_ty, cur_b;
+  {
+    const int r = cur_t / p.tw;
+    cur_tx = cur_t - r * p.tw; cur_b = r / p.th; cur_ty = r - cur_b * p.th;
+  }
+  auto load_raw = [&](int c) {
+    (void)c;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t = cur_t + e;
+      if (FAST || t < p.tiles) {
+        int tx = cur_tx + e, ty = cur_ty, b = cur_b;
+        if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
+        load_tile(e, tx, ty, b);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) d[q][e] = 0.f;

@@ -518,8 +518,10 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   // one tile of this wave's operand into element e of the pair registers.  INNER (wave-uniform, decided per tile): the whole
   // patch / dy tile lies inside its tensor after reflection, so no position needs a validity test -- true for every tile when
   // FAST, else for all but the ragged last tile row / column (and zero-padded borders)
-  auto load_tile_impl = [&](auto inner_tag, int e, int tx, int ty, int b) {
+  // (e travels as a type: a run-time index into the pair registers would send them to scratch memory)
+  auto load_tile_impl = [&](auto inner_tag, auto e_tag, int tx, int ty, int b) {
     constexpr bool INNER = decltype(inner_tag)::value;
+    constexpr int e = decltype(e_tag)::value;
         if (xside) {
           int ro[4], co[4];
 #pragma unroll
@@ -576,14 +578,16 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
           }
         }
   };
-  auto load_tile = [&](int e, int tx, int ty, int b) {
-    bool inner = FAST;
-    if constexpr (!FAST) {
+  auto load_tile = [&](auto e_tag, int tx, int ty, int b) {
+    if constexpr (FAST) {
+      load_tile_impl(std::true_type{}, e_tag, tx, ty, b);
+    } else {
+      bool inner;
       if constexpr (S2) inner = p.reflect && 6 * ty + 6 <= p.H && 6 * tx + 6 <= p.W && 3 * ty + 2 < p.Ho && 3 * tx + 2 < p.Wo;
       else inner = p.xo == -1 ? (p.reflect != 0) : (2 * ty + p.xo + 3 < p.H && 2 * tx + p.xo + 3 < p.W && p.xo >= 0);
+      if (inner) load_tile_impl(std::true_type{}, e_tag, tx, ty, b);
+      else load_tile_impl(std::false_type{}, e_tag, tx, ty, b);
     }
-    if (inner) load_tile_impl(std::true_type{}, e, tx, ty, b);
-    else load_tile_impl(std::false_type{}, e, tx, ty, b);
   };
   // tiles 2 pair, 2 pair + 1 of chunk c: everything but the lane's channel offset is wave-uniform (scalar unit).  The tile
   // coordinates are carried from chunk to chunk (load_raw is called for c = 0, 1, 2, ... in order: + 8 tiles each time)
@@ -593,22 +597,24 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
     const int r = cur_t / p.tw;
     cur_tx = cur_t - r * p.tw; cur_b = r / p.th; cur_ty = r - cur_b * p.th;
   }
+  auto load_one = [&](auto e_tag) {
+    constexpr int e = decltype(e_tag)::value;
+    const int t = cur_t + e;
+    if (FAST || t < p.tiles) {
+      int tx = cur_tx + e, ty = cur_ty, b = cur_b;
+      if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
+      load_tile(e_tag, tx, ty, b);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) d[q][e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NG; ++q) g[q][e] = 0.f;
+    }
+  };
   auto load_raw = [&](int c) {
     (void)c;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int t = cur_t + e;
-      if (FAST || t < p.tiles) {
-        int tx = cur_tx + e, ty = cur_ty, b = cur_b;
-        if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
-        load_tile(e, tx, ty, b);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) d[q][e] = 0.f;
-#pragma unroll
-        for (int q = 0; q < NG; ++q) g[q][e] = 0.f;
-      }
-    }
+    load_one(std::integral_constant<int, 0>{});
+    load_one(std::integral_constant<int, 1>{});
     cur_t += 8; cur_tx += 8;
     while (cur_tx >= p.tw) { cur_tx -= p.tw; if (++cur_ty >= p.th) { cur_ty = 0; ++cur_b; } }
   };

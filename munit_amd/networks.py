@@ -211,7 +211,9 @@ class ResBlock(nn.Module):
     def forward(self, x):
         # x feeds the first convolution and the skip connection; in backward the two gradients meet inside that convolution's
         # backward-data (ops.ResidualLink) instead of in a separate element-wise add
-        link = ops.ResidualLink() if (torch.is_grad_enabled() and x.requires_grad and ops.FUSE_SKIP_GRAD) else None
+        # (fp32 tensors only: the bf16-storage backward-data has no fused `add` on its folded path)
+        link = ops.ResidualLink() if (torch.is_grad_enabled() and x.requires_grad and ops.FUSE_SKIP_GRAD and
+                                      x.dtype == torch.float32) else None
         h = self.model[0](x, link_open=link)
         return self.model[1](h, residual=x, link_close=link)
 

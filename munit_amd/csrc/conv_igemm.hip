@@ -875,6 +875,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_WINOGRAD43) return wino43_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return cc * it.KH * it.KW + 4 * wino_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD)
     return 4 * wino_image_elems(it.Cin, it.Cout);
@@ -888,6 +889,7 @@ __host__ __device__ inline long long prep_trips(const PrepItem& it) {
   const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ||
                     it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return (long long)it.Cout * it.Cin * (it.KH * it.KW + 4);
+  if (it.kind == MUNIT_PREP_WINOGRAD43) return (long long)it.Cout * it.Cin;   // one trip = one channel pair, 36 elements
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -898,6 +900,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
       wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
+    else if (it.kind == MUNIT_PREP_WINOGRAD43) wino43_weight_item(it.w, it.wp, it.Cout, it.Cin, false, i);
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD) wino_s2_dgrad_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
@@ -1206,6 +1209,9 @@ bool wino_geometry_ok(const munit_conv_desc* d) {
          d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH;
 }
 bool wino_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
+// the same layers through F(4x4, 3x3) (conv_wino43.hip) where the extent is a multiple of 4 and Cin of 32: 36 instead of 64
+// multiply-accumulates per 16 outputs and channel pair
+bool wino43_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino43_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
 // MUNIT_WINO_S2_MIN_BLOCKS: developer override of the threshold (tests use 1 to push small shapes through the kernel)
 long long wino_s2_min_blocks() {
   static const long long v = getenv("MUNIT_WINO_S2_MIN_BLOCKS") ? atoll(getenv("MUNIT_WINO_S2_MIN_BLOCKS")) : 192;
@@ -1244,6 +1250,7 @@ munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* w
   if (small) return it;
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
   if (subpixel_ok(d)) it.kind = subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
+  else if (wino43_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD43;
   else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
   else if (wino_s2_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD_S2;
   else if (it.bf16) it.kind = MUNIT_PREP_CAST;
@@ -1260,7 +1267,7 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
   if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return munit_small_fwd_workspace(d);
-  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d) || wino_s2_fwd_ok(d)) return img;
+  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino43_fwd_ok(d) || wino_fwd_ok(d) || wino_s2_fwd_ok(d)) return img;
   if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
     const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
     return c.x4_bytes + c.w4_bytes;
@@ -1321,6 +1328,17 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.th = cdiv(Ho, 3); q.tw = cdiv(Wo, 3); q.bth = cdiv(q.th, 8); q.btw = cdiv(q.tw, 8); q.NB = d->Cout / 64;
     q.act = d->act; q.slope = d->slope;
     return munit_wino_launch(q, st);
+  }
+  if (it.kind == MUNIT_PREP_WINOGRAD43) {
+    WinoParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
+    q.y_sw = d->Cout; q.y_sh = (long long)d->W * d->Cout; q.y_sb = (long long)d->H * d->W * d->Cout;
+    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout; q.xc = d->Cin; q.cpp = d->Cin / 8;
+    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
+    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
+    q.th = d->H / 4; q.tw = d->W / 4; q.bth = cdiv(q.th, 4); q.btw = cdiv(q.tw, 4); q.NB = d->Cout / 64;
+    q.act = d->act; q.slope = d->slope;
+    return munit_wino43_launch(q, st);
   }
   if (it.kind == MUNIT_PREP_WINOGRAD) {
     WinoParams q{};
@@ -1852,6 +1870,7 @@ const char* munit_igemm_kernel_name(const munit_conv_desc* d, int pass) {
     if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return "conv_head_pk_kernel";
     if (subpixel_wino_ok(d)) return "conv_wino_kernel<1, 0> x4 sub-pixel phases + conv_igemm_kernel frame";
     if (subpixel_ok(d)) return "conv_igemm_kernel x4 sub-pixel phases + frame";
+    if (wino43_fwd_ok(d)) return refl ? "conv_wino43_kernel<0>" : "conv_wino43_kernel<1>";
     if (wino_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 0>" : "conv_wino_kernel<1, 0>";
     if (wino_s2_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 1>" : "conv_wino_kernel<1, 1>";
     if (cin4_fwd_ok(d)) return "conv_igemm_kernel<.., 5> (3 input channels as 4-channel taps)";
@@ -1878,6 +1897,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (pass == MUNIT_PASS_FWD) {
     if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    if (wino43_fwd_ok(d)) return cc * d->B * (d->H / 4) * (d->W / 4) * 36;   // F(4x4, 3x3): 36 products per 4x4 tile instead of 144
     if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36
     if (wino_s2_fwd_ok(d)) return 4 * cc * d->B * cdiv(Ho, 3) * cdiv(Wo, 3) * 16;   // per 3x3 tile and input phase
     if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile

@@ -876,6 +876,7 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_WINOGRAD43) return wino43_image_elems(it.Cin, it.Cout);
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) return 4 * wino43_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return cc * it.KH * it.KW + 4 * wino_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD)
     return 4 * wino_image_elems(it.Cin, it.Cout);
@@ -890,6 +891,7 @@ __host__ __device__ inline long long prep_trips(const PrepItem& it) {
                     it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return (long long)it.Cout * it.Cin * (it.KH * it.KW + 4);
   if (it.kind == MUNIT_PREP_WINOGRAD43) return (long long)it.Cout * it.Cin;   // one trip = one channel pair, 36 elements
+  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) return 4ll * it.Cout * it.Cin;
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -901,6 +903,7 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
       wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD43) wino43_weight_item(it.w, it.wp, it.Cout, it.Cin, false, i);
+    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) wino43_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD) wino_s2_dgrad_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
@@ -1243,13 +1246,18 @@ bool subpixel_wino_ok(const munit_conv_desc* d) {
          d->act != MUNIT_ACT_TANH && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout);
 }
 
+// ... and through F(4x4, 3x3) where the source extent is a multiple of 4
+bool subpixel_wino43_ok(const munit_conv_desc* d) {
+  return subpixel_wino_ok(d) && munit_wino43_ok(d->B, d->H, d->W, d->Cin, d->Cout);
+}
+
 // forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
 munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* wp) {
   munit_prep_item it{w, wp, d->Cout, d->KH, d->KW, d->Cin, MUNIT_PREP_NONE, 1, 0};
   const bool small = munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD");
   if (small) return it;
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
-  if (subpixel_ok(d)) it.kind = subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
+  if (subpixel_ok(d)) it.kind = subpixel_wino43_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD43 : subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
   else if (wino43_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD43;
   else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
   else if (wino_s2_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD_S2;
@@ -1381,7 +1389,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     p.Ktot = c.kpad; p.w_row = c.kpad; p.cin4 = 1;
     return launch_igemm<0>(p, 1, st);
   }
-  if (it.kind == MUNIT_PREP_SUBPIXEL || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
+  if (it.kind == MUNIT_PREP_SUBPIXEL || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
     IgemmParams q = p;
@@ -1396,7 +1404,18 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.w_phase = (long long)d->Cout * q.Ktot;
     q.y_phase_row = (long long)Wo * d->Cout;
     q.y_phase_col = d->Cout;
-    if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
+    if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) {
+      WinoParams wq{};
+      wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
+      wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
+      wq.u_phase = wino43_image_elems(d->Cin, d->Cout); wq.y_prow = q.y_phase_row; wq.y_pcol = q.y_phase_col; wq.phases = 4;
+      wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout; wq.xc = d->Cin; wq.cpp = d->Cin / 8;
+      wq.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
+      wq.mode = 1;
+      wq.th = d->H / 4; wq.tw = d->W / 4; wq.bth = cdiv(wq.th, 4); wq.btw = cdiv(wq.tw, 4); wq.NB = d->Cout / 64;
+      wq.act = d->act; wq.slope = d->slope;
+      rc = munit_wino43_launch(wq, st);
+    } else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
       WinoParams wq{};
       wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
       wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
@@ -1828,21 +1847,22 @@ extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, i
 
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
-  const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
-  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD;
+  const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD || item->kind == MUNIT_PREP_WINOGRAD43;
+  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD ||
+                   item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43;
   const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2 || item->kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 &&
                            (item->kind == MUNIT_PREP_WINOGRAD_S2 ? item->Cin % 8 == 0 && item->Cout % 64 == 0
                                                                  : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
                   "conv2d_prepare_weights: stride-2 Winograd image needs a 4x4 fp32 filter, K %% 8 == 0, N %% 64 == 0");
   MUNIT_CHECK_ARG(!spw || (item->KH == 5 && item->KW == 5 && !item->bf16 &&
-                           (item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
+                           (item->kind != MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
                                                                        : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
                   "conv2d_prepare_weights: sub-pixel Winograd image needs a 5x5 fp32 filter, Cin %% 8 == 0, Cout %% 64 == 0");
   MUNIT_CHECK_ARG(item->kind == MUNIT_PREP_DGRAD || item->kind == MUNIT_PREP_SUBPIXEL || wino || spw || ws2 || (item->kind == MUNIT_PREP_CAST && item->bf16),
                   "conv2d_prepare_weights: bad kind %d", item->kind);
   MUNIT_CHECK_ARG(!wino || (item->KH == 3 && item->KW == 3 && !item->bf16 &&
-                            (item->kind == MUNIT_PREP_WINOGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
+                            (item->kind != MUNIT_PREP_WINOGRAD_DGRAD ? item->Cin % 8 == 0 && item->Cout % 64 == 0
                                                                : item->Cout % 8 == 0 && item->Cin % 64 == 0)),
                   "conv2d_prepare_weights: Winograd image needs a 3x3 fp32 filter, K %% 8 == 0, N %% 64 == 0");
   MUNIT_CHECK_ARG(item->ps >= 1 && item->KH % item->ps == 0 && item->KW % item->ps == 0, "conv2d_prepare_weights: bad phase count");
@@ -1868,6 +1888,7 @@ const char* munit_igemm_kernel_name(const munit_conv_desc* d, int pass) {
   const bool refl = d->pad_mode == MUNIT_PAD_REFLECT;
   if (pass == MUNIT_PASS_FWD) {
     if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return "conv_head_pk_kernel";
+    if (subpixel_wino43_ok(d)) return "conv_wino43_kernel<1> x4 sub-pixel phases + conv_igemm_kernel frame";
     if (subpixel_wino_ok(d)) return "conv_wino_kernel<1, 0> x4 sub-pixel phases + conv_igemm_kernel frame";
     if (subpixel_ok(d)) return "conv_igemm_kernel x4 sub-pixel phases + frame";
     if (wino43_fwd_ok(d)) return refl ? "conv_wino43_kernel<0>" : "conv_wino43_kernel<1>";
@@ -1895,6 +1916,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
+    if (subpixel_wino43_ok(d)) return cc * d->B * ((double)(d->H / 4) * (d->W / 4) * 4 * 36 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (wino43_fwd_ok(d)) return cc * d->B * (d->H / 4) * (d->W / 4) * 36;   // F(4x4, 3x3): 36 products per 4x4 tile instead of 144

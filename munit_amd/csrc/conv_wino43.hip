@@ -35,7 +35,10 @@ namespace {
 constexpr int F43 = 36;
 constexpr int T43 = 16;                          // tiles per block (4 x 4)
 constexpr int KC43 = 32;                         // channels per chunk
-constexpr int VBUF43 = F43 * 4 * T43 * 8;        // floats per V buffer: [f][sub-step 4][tile 16][8 k]  (72 KiB)
+constexpr int VSUB43 = F43 * T43 * 8 + 8;        // floats per sub-step slab [f][tile 16][8 k] + 8: the pad keeps the four
+                                                 // sub-steps' reads of a frequency from being a multiple of 512 B apart, or the
+                                                 // compiler fuses pairs into ds_read2st64_b64, which banks mod 32 in 16-lane groups
+constexpr int VBUF43 = 4 * VSUB43;               // floats per V buffer: [sub-step 4][f][tile][8 k]  (72 KiB)
 constexpr int MLD43 = 68;                        // row stride of the epilogue planes M[f][tile][64 channels]
 constexpr int SMEM43 = F43 * T43 * MLD43;        // 39 168 floats = 156 672 B  (>= 2 * VBUF43 = 147 456 B)
 static_assert(SMEM43 >= 2 * VBUF43, "operand buffers must fit");
@@ -114,23 +117,28 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   f32x2 d[36];
   auto load_raw = [&](int c) {
+#ifdef ABL43_NO_RAW     // timing-only ablation: the patch is loaded once
+    if (c > 1) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         d[i * 6 + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, roff[i] + coff[j], c * (KC43 * 4), 0));
   };
-  // V position of this loader lane in plane f of sub-step `wave`: [tile][8 k] with the k-pair slot swizzled by the tile's bit 3
+  // V position of this loader lane in plane f of sub-step slab `wave`: [tile][8 k] with the k-pair slot swizzled by the tile's bit 3
   // (the half-wave fragment reads below then cover all 64 banks)
-  const int vpos = (wave * T43 + tl) * 8 + ((cp ^ (((tl >> 3) & 1) << 1)) << 1);
+  const int vpos = wave * VSUB43 + tl * 8 + ((cp ^ (((tl >> 3) & 1) << 1)) << 1);
   auto transform_store = [&](int buf) {
+#ifndef ABL43_NO_XFORM   // timing-only ablation: no transform arithmetic
 #pragma unroll
     for (int j = 0; j < 6; ++j) bt6<6>(d + j);        // columns: B^T d
 #pragma unroll
     for (int i = 0; i < 6; ++i) bt6<1>(d + i * 6);    // rows: (.) B
+#endif
     float* V = smem + buf * VBUF43 + vpos;
 #pragma unroll
-    for (int f = 0; f < F43; ++f) *reinterpret_cast<f32x2*>(V + f * (4 * T43 * 8)) = d[f];
+    for (int f = 0; f < F43; ++f) *reinterpret_cast<f32x2*>(V + f * (T43 * 8)) = d[f];
   };
 
   // ---- the two roles as two instantiations of one body: NF = frequencies of the wave (3 loader / 6 multiply-only), so that
@@ -146,6 +154,12 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
     const long long u_c8 = (long long)p.NB * F43 * 128;   // f32x4 per 8-channel step
     f32x4 u0[NF][2], u1[NF][2];
     auto load_u = [&](int c8, f32x4 (&u)[NF][2]) {
+#ifdef ABL43_NO_U      // timing-only ablation: the weight fragments are loaded once
+      if (c8 > 1) return;
+#endif
+#ifdef ABL43_U_SAME    // timing-only ablation: every sub-step reads the same 2 slices of the image (cache hits), same instruction count
+      c8 &= 1;
+#endif
       const f32x4* g = ug + c8 * u_c8;
 #pragma unroll
       for (int q = 0; q < NF; ++q)
@@ -162,12 +176,12 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
     int fpos[NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-      fpos[q] = ((f0 + q) * (4 * T43 * 8) + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) << 1)) * 4;
+      fpos[q] = ((f0 + q) * (T43 * 8) + (lane & 15) * 8 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) << 1)) * 4;
       asm("" : "+v"(fpos[q]));
     }
     auto compute = [&](const int (&fb)[NF], auto s_tag, const f32x4 (&u)[NF][2]) {
       constexpr int S = decltype(s_tag)::value;
-      const char* Vb = reinterpret_cast<const char*>(smem) + S * (T43 * 8 * 4);
+      const char* Vb = reinterpret_cast<const char*>(smem) + S * (VSUB43 * 4);
       f32x2 a[NF];
 #pragma unroll
       for (int q = 0; q < NF; ++q) a[q] = *reinterpret_cast<const f32x2*>(Vb + fb[q]);
@@ -192,10 +206,12 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
     for (int c = 0; c < nc; ++c) {
       const int cur = c & 1;
       if constexpr (LD) {
+#ifndef ABL43_NO_LOADER   // timing-only ablation: the loader waves only multiply
         if (c + 1 < nc) {
           transform_store(cur ^ 1);
           if (c + 2 < nc) load_raw(c + 2);
         }
+#endif
       }
       int fb[NF];
 #pragma unroll
@@ -209,7 +225,9 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
       compute(fb, std::integral_constant<int, 2>{}, u0);
       if (c + 1 < nc) load_u(4 * c + 4, u0);
       compute(fb, std::integral_constant<int, 3>{}, u1);
+#ifndef ABL43_NO_BARRIER  // timing-only ablation
       __syncthreads();
+#endif
     }
     // epilogue, first half: this wave's planes M[f][tile][64 channels] into LDS
 #pragma unroll
@@ -224,6 +242,9 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
   else body(std::integral_constant<int, 6>{}, std::false_type{});
 
   // ---- epilogue: every thread folds the 36 planes of two (tile, channel) pairs into 4x4 pixels ----
+#ifdef ABL43_NO_EPI       // timing-only ablation: no output transform / stores
+  if (p.K > 0) return;
+#endif
   __syncthreads();
   const int co = tid & 63;
   const int n = n_blk * 64 + co;

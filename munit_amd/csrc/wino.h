@@ -209,6 +209,47 @@ __device__ inline void wino43_weight_item(const float* __restrict__ w, float* __
     for (int q = 0; q < 6; ++q) o[(i * 6 + q) * 512] = row[q];
   }
 }
+// 36 frequencies of the 3x3 filter g in the image order
+__device__ inline void wino43_store_item(float* __restrict__ img, long long j, const float (&g)[3][3]) {
+  float t[6][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float col[6];
+    wino43_g1d(g[0][s], g[1][s], g[2][s], col);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][s] = col[i];
+  }
+  float* o = img + (j >> 9) * (36 * 512) + (j & 511);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float row[6];
+    wino43_g1d(t[i][0], t[i][1], t[i][2], row);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[(i * 6 + q) * 512] = row[q];
+  }
+}
+// sub-pixel up-sampling layer (see wino_subpixel_weight_item): [phase 4][the 36-frequency image of that phase's merged 3x3 filter]
+__device__ inline void wino43_subpixel_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
+  const long long per = (long long)Cin * Cout;
+  const int ph = (int)(j / per), a = ph >> 1, b = ph & 1;
+  int k, no;
+  wino_item_index(j - ph * per, Cout, k, no);
+  float g[3][3];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
+      const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
+      const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
+      const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
+      float s = 0.f;
+      for (int kh = h0; kh < h0 + hn; ++kh)
+        for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)no * 5 + kh) * 5 + kw) * Cin + k];
+      g[dh][dw] = s;
+    }
+  wino43_store_item(img + ph * wino43_image_elems(Cin, Cout), j - ph * per, g);
+}
 bool munit_wino43_ok(int B, int H, int W, int K, int N);
 
 struct WinoParams {

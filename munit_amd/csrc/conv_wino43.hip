@@ -284,8 +284,12 @@ __global__ __launch_bounds__(512) void conv_wino43_kernel(WinoParams p) {
 
 }  // namespace
 
+// OPT-IN (environment MUNIT_WINOGRAD43=1, read once per process).  Measured in round 3 on the trunk layer: 148 us against 176 us
+// for F(2x2, 3x3) forward (-16 %; bench step 106.3 vs 107.9 ms), at 8e-6 against 7e-7 normalised max error; with it the
+// step-level gradient parity sits at 1.7e-5 .. 3.5e-5 (bound 5e-5) instead of 4e-6 and the full-size adjoint test needs a looser
+// bound.  Parity is the first gate of this build, so the default stays the exact-to-1e-6 F(2x2, 3x3) path.
 bool munit_wino43_ok(int B, int H, int W, int K, int N) {
-  if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD") || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD43")) return false;
+  if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINOGRAD") || !MUNIT_ENV_FLAG("MUNIT_WINOGRAD43")) return false;
   return K % KC43 == 0 && N % 64 == 0 && H % 4 == 0 && W % 4 == 0 && H >= 4 && W >= 4 &&
          (long long)B * H * W * K < (1ll << 28) && (long long)B * H * W * N < (1ll << 40);
 }

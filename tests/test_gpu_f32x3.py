@@ -1,7 +1,8 @@
 """GPU: the opt-in "f32x3" compute mode (fp32 operands split exactly into three bf16 planes, six product terms on
 the bf16 matrix pipe, fp32 accumulation) must pass the SAME parity tests at the SAME tolerances as the native
 fp32 MFMA kernels: one convolution case per kernel family of test_gpu_ops.py (2e-5 forward, 1e-4 gradients vs the fp64
-oracle) and the step-level parity against the oracle.  The mode is slower than the native Winograd path since round 2 and is
+oracle).  (The step-level parity run of this mode was dropped in round 3: the mode is slower than the native Winograd path and the
+suite's time goes to the fp32 hot path.)  The mode is slower than the native Winograd path since round 2 and is
 kept as a supplementary arithmetic only; these tests are collected LAST (tests/conftest.py)."""
 import pytest
 import torch
@@ -68,9 +69,3 @@ def test_resblock_size_accuracy_vs_native():
     for a, b in zip(errs["f32x3"], errs["f32"]):
         assert a <= max(2.0 * b, 2e-6), errs     # native = Winograd for this shape now (fwd / dgrad ~7e-7)
     assert max(errs["f32x3"]) <= 5e-6, errs
-
-
-def test_step_parity_f32x3():
-    """dis_update + gen_update against the oracle with the tolerances of the fp32 step test."""
-    from tests.parity import run_step_parity
-    run_step_parity(size=64, batch=2, gen_state=1, iters=1, device=torch.device("cuda:0"), precision="f32x3")

@@ -37,7 +37,8 @@ def test_modules_match_golden_forward(golden, gs):
         assert nerr(o, torch.from_numpy(arrays[key + "_dis%d" % i])) <= 1e-4
 
 
-@pytest.mark.parametrize("gs,iters", [(1, 3), (0, 1)])   # the iterations run the fp64 oracle on the host: ~30 s each
+@pytest.mark.parametrize("gs,iters", [(1, 2), (0, 1)])   # the iterations run the fp64 oracle on the host: ~30 s each;
+# two iterations cross the StepLR boundary (step_size 2) and carry Adam moments; tools/parity_report.py runs three
 def test_step_matches_oracle(gs, iters):
     """dis_update + gen_update vs the fp64 oracle: losses 1e-5, EVERY gradient tensor within SURVEY.md 8c's 1e-2
     (ReLU / LeakyReLU branches pinned to the HIP forward, tests/parity.py::GradCheck), Adam moments, weight step."""

@@ -494,6 +494,109 @@ __global__ void small_slab_reduce_kernel(const float* __restrict__ slab, float* 
 }  // namespace
 
 // ---- entry points used by the conv dispatch in conv_igemm.hip / conv_wgrad.hip (not part of the C ABI) ----
+// Round 3: the same backward-weight with PACKED fp32 FMAs.  A wave walks TWO output rows at once -- lanes 0-31 row oh, lanes
+// 32-63 row oh + 1 -- and a lane owns a channel PAIR, so every multiply-accumulate of the 3 x 7 window products is one
+// v_pk_fma_f32 over the pair: 21 vector instructions per two pixels where the scalar form issues 42 (+ 6 v_readlane), the
+// dy value of a lane's own row arrives by ds_bpermute (LDS pipe) instead of readlane + select.  The two half-waves hold partial
+// sums of the same 64 channels; they meet through one cross-half shuffle per accumulator at the end.  Same slabs, same
+// reduction kernel, same summation over rows inside a band up to the pairing of rows.
+namespace {
+template <int CO, int K, typename XT>
+__global__ __launch_bounds__(256) void conv_lanes_wgrad_pk_kernel(SmallParams p) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = p.Cin >> 6;
+  const long long unit = (long long)blockIdx.x * 4 + wv;
+  const long long per_band = (long long)K * G;
+  const long long nunits = (long long)p.B * p.units_per_img * per_band;
+  if (unit >= nunits) return;  // no block-level synchronisation below
+  const int g = (int)(unit % G);
+  const int kh = (int)((unit / G) % K);
+  const long long band = unit / per_band;          // (b, band index)
+  const int bi = (int)(band % p.units_per_img);
+  const int b = (int)(band / p.units_per_img);
+  const int rh = lane >> 5, cp = lane & 31;         // row of the pair, channel pair
+  const int ci = g * 64 + 2 * cp;
+  const bool want_b = g == 0 && kh == 0;
+
+  f32x2 acc[CO][K];
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) acc[c][kw] = f32x2{0.f, 0.f};
+  float bsum[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) bsum[c] = 0.f;
+
+  auto ldx = [&](const XT* q) -> f32x2 {
+    if constexpr (sizeof(XT) == 4) return *reinterpret_cast<const f32x2*>(q);
+    else { const bf16_t* h = reinterpret_cast<const bf16_t*>(q); return f32x2{(float)h[0], (float)h[1]}; }
+  };
+  constexpr int CH = (32 / K) * K;  // pixels per dy fetch (32 lanes per row): a multiple of K keeps the rotation phase
+  const int oh_begin = bi * p.rows_per_unit, oh_end = min(p.Ho, oh_begin + p.rows_per_unit);
+  for (int oh2 = oh_begin; oh2 < oh_end; oh2 += 2) {
+    const int oh = oh2 + rh;
+    const bool live = oh < oh_end;                 // an odd row count leaves the second half-wave idle in the last pair
+    const int ih = map_coord(min(oh, p.Ho - 1) - p.pad + kh, p.H, p.reflect);
+    const bool rowok = live && ih >= 0;
+    const XT* rowp = reinterpret_cast<const XT*>(p.x) + ((long long)b * p.H + (rowok ? ih : 0)) * p.W * p.Cin + ci;
+    const float* dyrow = p.dy + ((long long)b * p.Ho + min(oh, p.Ho - 1)) * p.Wo * CO;
+    f32x2 win[K];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+      const int iw = map_coord(j - p.pad, p.W, p.reflect);
+      win[j] = (rowok && iw >= 0) ? ldx(rowp + (long long)iw * p.Cin) : f32x2{0.f, 0.f};
+    }
+    for (int ow0 = 0; ow0 < p.Wo; ow0 += CH) {
+      const int n = min(CH, p.Wo - ow0);
+      float dyv[CO];   // lane (rh, j) holds pixel ow0 + j of its row
+#pragma unroll
+      for (int c = 0; c < CO; ++c) dyv[c] = (live && cp < n) ? dyrow[(long long)(ow0 + cp) * CO + c] : 0.f;
+#pragma unroll 1
+      for (int i0 = 0; i0 < n; i0 += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+          const int i = i0 + s;  // pixels past n carry dy = 0 (lanes >= n loaded 0) and clamped loads
+          const int iw = map_coord(min(ow0 + i, p.Wo - 1) + (K - 1) - p.pad, p.W, p.reflect);
+          win[(K - 1 + s) % K] = (rowok && iw >= 0) ? ldx(rowp + (long long)iw * p.Cin) : f32x2{0.f, 0.f};
+          const int src = ((lane & 32) + min(i, 31)) << 2;   // byte index of the lane holding pixel i of this lane's row
+#pragma unroll
+          for (int c = 0; c < CO; ++c) {
+            const float d = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, dyv[c])));
+            if (want_b) bsum[c] += d;
+            const f32x2 dd = {d, d};
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) acc[c][kw] = __builtin_elementwise_fma(dd, win[(kw + s) % K], acc[c][kw]);
+          }
+        }
+      }
+    }
+  }
+  // the two half-waves hold partial sums of the same channel pairs: add across (lane ^ 32); lanes 0-31 store
+  const long long n_w = (long long)CO * K * K * p.Cin;
+  float* out = p.slab + band * (n_w + CO);
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      f32x2 v = acc[c][kw];
+      v[0] += __shfl_xor(v[0], 32, 64);
+      v[1] += __shfl_xor(v[1], 32, 64);
+      if (rh == 0) *reinterpret_cast<f32x2*>(out + ((long long)(c * K + kh) * K + kw) * p.Cin + ci) = v;
+    }
+  if (want_b) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float t = bsum[c] + __shfl_xor(bsum[c], 32, 64);   // every lane of a half saw the same dy sequence
+      v = (lane == c) ? t : v;
+    }
+    if (lane < CO) out[n_w + lane] = v;
+  }
+}
+}  // namespace
+
 bool munit_small_fwd_supported(const munit_conv_desc* d) {
   return d->Cout == 3 && d->KH == 7 && d->KW == 7 && d->stride == 1 && d->upsample == 0 && d->Cin % 16 == 0;
 }
@@ -561,8 +664,14 @@ int munit_small_wgrad(const munit_conv_desc* d, int Ho, int Wo, const void* x, c
   const int G = d->Cin / 64;
   const long long bands = (long long)d->B * p.units_per_img;
   const long long units = bands * 7 * G;
-  if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, bf16_t>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, float>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  const bool pk = !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_PK");
+  if (pk) {
+    if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_lanes_wgrad_pk_kernel<3, 7, bf16_t>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_lanes_wgrad_pk_kernel<3, 7, float>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  } else {
+    if (d->in_dtype == MUNIT_DTYPE_BF16) hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, bf16_t>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_lanes_wgrad_kernel<3, 7, float>), dim3((unsigned)cdiv(units, 4)), dim3(256), 0, st, p);
+  }
   MUNIT_CHECK_LAUNCH("conv_lanes_wgrad");
   const long long n_w = (long long)3 * 49 * d->Cin;
   const int blocks = cdiv(n_w + 3, 256);

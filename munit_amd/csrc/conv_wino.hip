@@ -169,18 +169,24 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
   };
   const int vpos = tl * 8 + ((cp ^ (((tl >> 3) & 1) << 1) ^ ((tl >> 4) & 3)) << 1);
   const bool e_top = gy == 0, e_bot = gy == p.th - 1, e_left = gx == 0, e_right = gx == p.tw - 1;
+  const bool blk_tb = bty == 0 || bty == p.bth - 1, blk_lr = btx == 0 || btx == p.btw - 1;   // block touches the top / bottom, left / right border
   auto transform_store = [&](int buf) {
     const f32x2 z = {0.f, 0.f};
     if constexpr (MODE == 2) {
+      // only blocks on the image border hold edge tiles: the others skip the fold (block-uniform branches)
+      if (blk_tb) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        d[12 + j] += e_top ? d[4 + j] : z;
-        d[0 + j] += e_bot ? d[8 + j] : z;
+        for (int j = 0; j < 4; ++j) {
+          d[12 + j] += e_top ? d[4 + j] : z;
+          d[0 + j] += e_bot ? d[8 + j] : z;
+        }
       }
+      if (blk_lr) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        d[i * 4 + 3] += e_left ? d[i * 4 + 1] : z;
-        d[i * 4 + 0] += e_right ? d[i * 4 + 2] : z;
+        for (int i = 0; i < 4; ++i) {
+          d[i * 4 + 3] += e_left ? d[i * 4 + 1] : z;
+          d[i * 4 + 0] += e_right ? d[i * 4 + 2] : z;
+        }
       }
     }
     f32x2 u[16];
@@ -725,13 +731,17 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
   for (int c = 0; c < nc; ++c) {
     const int cur = c & 1;
     const bool more = c + 1 < nc;
-    if (more && wave < 4) {
+#ifndef WG_ORDER
+#define WG_ORDER 0     // 0: input-side waves transform before their MFMAs, dy-side after (measured best); 1: all before; 2: swapped
+#endif
+    const bool first = WG_ORDER == 1 ? true : (WG_ORDER == 2 ? wave >= 4 : wave < 4);
+    if (more && first) {
       transform_store(cur ^ 1);
       if (c + 2 < nc) load_raw(c + 2);
     }
     compute(cur, 0);
     compute(cur, 1);
-    if (more && wave >= 4) {
+    if (more && !first) {
       transform_store(cur ^ 1);
       if (c + 2 < nc) load_raw(c + 2);
     }

@@ -44,8 +44,8 @@ struct IgemmParams {
   // ROLE 2 (backward-data with the pad/upsample adjoint folded into the gather): geometry of the
   // forward conv whose input gradient is being formed
   int f_pad, f_ups, f_reflect, f_Hu, f_Wu;
-  // frame mode (sub-pixel up-sampling conv): GEMM rows enumerate only the 2-pixel border frame of the
-  // Ho x Wo output (rows 0,1,Ho-2,Ho-1 in full, then columns 0,1,Wo-2,Wo-1 of the remaining rows)
+  // frame mode (sub-pixel up-sampling conv): GEMM rows enumerate only the border frame of the Ho x Wo output, `frame`
+  // pixels wide (2: rows 0,1,Ho-2,Ho-1 in full, then columns 0,1,Wo-2,Wo-1 of the remaining rows; 1: the outermost ring)
   int frame;
   // split-K (small grids): blockIdx.z = split, K-tiles [z*kt_per_split, ...); raw partial tiles go to
   // slab[(phase*ksplit + z)][M][Cout] and splitk_epilogue_kernel sums them in order (+bias, act)
@@ -77,18 +77,19 @@ __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, in
     oh = rem / Wo;
     ow = rem - oh * Wo;
   } else {
-    const int nb = 4 * Wo + 4 * (Ho - 4);
+    const int F = frame, F2 = 2 * frame;   // ring width (2, or 1 when the phase convs replicate the source edge)
+    const int nb = F2 * Wo + F2 * (Ho - F2);
     b = m / nb;
     int r = m - b * nb;
-    if (r < 4 * Wo) {
+    if (r < F2 * Wo) {
       const int q = r / Wo;
       ow = r - q * Wo;
-      oh = q < 2 ? q : Ho - 4 + q;
+      oh = q < F ? q : Ho - F2 + q;
     } else {
-      r -= 4 * Wo;
-      const int q = r & 3;
-      oh = 2 + (r >> 2);
-      ow = q < 2 ? q : Wo - 4 + q;
+      r -= F2 * Wo;
+      const int rr = r / F2, q = r - rr * F2;
+      oh = F + rr;
+      ow = q < F ? q : Wo - F2 + q;
     }
   }
 }
@@ -1281,7 +1282,8 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
     return c.x4_bytes + c.w4_bytes;
   }
   if (subpixel_ok(d))   // split-K slabs of the frame launch (few tiles, 25-tap K)
-    return img + splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1);
+    return img + std::max(splitk_bytes(d->B * (4 * Wo + 4 * (Ho - 4)), d->Cout, d->KH * d->KW * d->Cin, 1),     // 2-pixel frame
+                          splitk_bytes(d->B * (2 * Wo + 2 * (Ho - 2)), d->Cout, d->KH * d->KW * d->Cin, 1));    // 1-pixel ring (F(2x2,3x3) phases)
   return img + splitk_bytes(d->B * Ho * Wo, d->Cout, d->KH * d->KW * d->Cin, 1);
 }
 
@@ -1393,6 +1395,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
     IgemmParams q = p;
+    int ring = 2;                             // width of the frame the generic gather recomputes
     q.ups = 0; q.Hu = d->H; q.Wu = d->W;
     q.Ho = d->H; q.Wo = d->W;                 // one GEMM row per source pixel and phase
     q.KH = 3; q.KW = 3; q.pad = 1; q.reflect = 0;
@@ -1423,6 +1426,12 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
       wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout; wq.xc = d->Cin; wq.cpp = d->Cin / 8;
       wq.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
       wq.mode = 1;
+      // the phase convolutions REPLICATE the source edge instead of padding with zeros: with x[-1] := x[0] the merged 3x3
+      // filters reproduce reflect(2) o nearest-upsample exactly for every output row / column but the outermost one (row 1
+      // reads up[-1] = up[1] = x[0], which is what the replicated pixel holds; row 0 reads up[-2] = up[2] = x[1], which it is
+      // not), so the 25-tap frame launch below recomputes a ring one pixel wide instead of two
+      wq.edge = 1;
+      ring = 1;
       wq.th = d->H / 2; wq.tw = d->W / 2; wq.bth = cdiv(wq.th, 8); wq.btw = cdiv(wq.tw, 8); wq.NB = d->Cout / 64;
       wq.act = d->act; wq.slope = d->slope;
       rc = munit_wino_launch(wq, st);
@@ -1430,8 +1439,8 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
       rc = launch_igemm<0>(q, 4, st);
     }
     if (rc) return rc;
-    p.frame = 1;
-    p.M = d->B * (4 * Wo + 4 * (Ho - 4));
+    p.frame = ring;
+    p.M = d->B * (2 * ring * Wo + 2 * ring * (Ho - 2 * ring));
     // the frame launch multiplies by the original 5x5 weights: fp32 -> w itself; bf16 storage -> their bf16 copy,
     // which the image carries behind the merged phase weights
     p.w = it.bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(wimg) + (size_t)4 * 9 * d->Cout * d->Cin) : w;
@@ -1726,7 +1735,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
       wq.act = MUNIT_ACT_NONE; wq.slope = 0.f;
       rc = munit_wino_launch(wq, st);
       if (rc) return rc;
-      p.frame = 1;
+      p.frame = 2;
       p.M = d->B * (4 * d->W + 4 * (d->H - 4));
       rc = launch_igemm<2>(p, 1, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
     } else if (pl.boxsum) {
@@ -1746,7 +1755,7 @@ extern "C" int munit_conv2d_dgrad_prepared(const munit_conv_desc* d, const void*
       rc = launch_igemm<0>(q, 1, st);
       if (rc) return rc;
       // the 2-pixel frame keeps the general folded gather (reflections add further positions there), split over K
-      p.frame = 1;
+      p.frame = 2;
       p.M = d->B * (4 * d->W + 4 * (d->H - 4));
       rc = launch_igemm<2>(p, 1, st, reinterpret_cast<char*>(ws) + pl.wt_bytes + pl.g_bytes, pl.sk_bytes);
     } else {
@@ -1917,7 +1926,7 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
     if (subpixel_wino43_ok(d)) return cc * d->B * ((double)(d->H / 4) * (d->W / 4) * 4 * 36 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
-    if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (2.0 * Wo + 2.0 * (Ho - 2)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (wino43_fwd_ok(d)) return cc * d->B * (d->H / 4) * (d->W / 4) * 36;   // F(4x4, 3x3): 36 products per 4x4 tile instead of 144
     if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36

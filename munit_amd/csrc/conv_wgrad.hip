@@ -31,7 +31,7 @@ struct WgradParams {
   long long dy_sb, dy_sh;
   int dy_sw;
   long long dy_off;
-  int frame;  // GEMM rows enumerate only the 2-pixel border frame of the Ho x Wo output (see decode_pixel)
+  int frame;  // > 0: GEMM rows enumerate only the border frame of the Ho x Wo output, `frame` pixels wide (see decode_pixel)
   unsigned x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST loader (0 when >= 2 GiB)
   int ct;                      // compute type (FAST variants only): 0 fp32 MFMA, 1 bf16 operands, 2 f32x3
   int x_bf16, dy_bf16;         // element types in HBM (FAST loader only)
@@ -50,18 +50,19 @@ __device__ inline void decode_pixel(int m, int Ho, int Wo, int frame, int& b, in
     oh = rem / Wo;
     ow = rem - oh * Wo;
   } else {
-    const int nb = 4 * Wo + 4 * (Ho - 4);
+    const int F = frame, F2 = 2 * frame;   // ring width in pixels
+    const int nb = F2 * Wo + F2 * (Ho - F2);
     b = m / nb;
     int r = m - b * nb;
-    if (r < 4 * Wo) {
+    if (r < F2 * Wo) {
       const int q = r / Wo;
       ow = r - q * Wo;
-      oh = q < 2 ? q : Ho - 4 + q;
+      oh = q < F ? q : Ho - F2 + q;
     } else {
-      r -= 4 * Wo;
-      const int q = r & 3;
-      oh = 2 + (r >> 2);
-      ow = q < 2 ? q : Wo - 4 + q;
+      r -= F2 * Wo;
+      const int rr = r / F2, q = r - rr * F2;
+      oh = F + rr;
+      ow = q < F ? q : Wo - F2 + q;
     }
   }
 }
@@ -1073,21 +1074,24 @@ bool subpixel_wgrad_ok(const munit_conv_desc* d) {
 struct SubpixelPlan {
   WgradPlan phase, frame;
   size_t dwc_bytes, slab_bytes;
-  bool wino;   // the four phase gradients (3x3 VALID over the interior source pixels) through the Winograd kernel
+  bool wino;   // the four phase gradients through the Winograd kernel
+  int ring;    // width of the output frame the generic 25-tap launch covers
 };
 void plan_subpixel(const munit_conv_desc* d, SubpixelPlan* sp) {
   const bool aligned = d->Cin % 4 == 0;
   plan_launch(d->B * (d->H - 2) * (d->W - 2), 9 * d->Cin, d->Cout, aligned, &sp->phase);
   const int Ho = 2 * d->H, Wo = 2 * d->W;
-  plan_launch(d->B * (4 * Wo + 4 * (Ho - 4)), 25 * d->Cin, d->Cout, aligned, &sp->frame);
-  sp->dwc_bytes = align_up((size_t)4 * d->Cout * 9 * d->Cin * sizeof(float), 256);
-  sp->slab_bytes = std::max(sp->phase.slab_bytes + sp->phase.bias_bytes, sp->frame.slab_bytes + sp->frame.bias_bytes);
   sp->wino = d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 && d->H >= 4 &&
              d->W >= 4 && munit_wino_wgrad_ok(d->B, d->H, d->W, d->Cin, d->Cout) &&
              (long long)d->B * 4 * d->H * d->W * d->Cout < (1ll << 29);
+  // Winograd phases run over ALL source pixels with a replicated edge and the outermost ring of dy masked (see
+  // munit_conv2d_wgrad): the generic 25-tap launch then covers a ring one pixel wide instead of two
+  sp->ring = sp->wino ? 1 : 2;
+  plan_launch(d->B * (2 * sp->ring * Wo + 2 * sp->ring * (Ho - 2 * sp->ring)), 25 * d->Cin, d->Cout, aligned, &sp->frame);
+  sp->dwc_bytes = align_up((size_t)4 * d->Cout * 9 * d->Cin * sizeof(float), 256);
+  sp->slab_bytes = std::max(sp->phase.slab_bytes + sp->phase.bias_bytes, sp->frame.slab_bytes + sp->frame.bias_bytes);
   if (sp->wino)
-    sp->slab_bytes = std::max(sp->slab_bytes, munit_wino_wgrad_workspace((long long)d->B * ((d->H - 2) / 2) * ((d->W - 2) / 2),
-                                                                            d->Cin, d->Cout, 4));
+    sp->slab_bytes = std::max(sp->slab_bytes, munit_wino_wgrad_workspace((long long)d->B * (d->H / 2) * (d->W / 2), d->Cin, d->Cout, 4));
 }
 
 // 3x3 / stride 1 / pad 1 fp32 layers with 64-multiples of channels: Winograd backward-weight (conv_wino.hip)
@@ -1137,7 +1141,8 @@ extern "C" double munit_conv2d_executed_flops(const munit_conv_desc* d, int pass
   if (subpixel_wgrad_ok(d)) {  // 4 phase gradients over the interior source pixels + the 25-tap frame
     SubpixelPlan sp;
     plan_subpixel(d, &sp);
-    return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * (sp.wino ? 4 : 9) + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
+    if (sp.wino) return cc * d->B * ((double)d->H * d->W * 4 * 4 + (2.0 * Wo + 2.0 * (Ho - 2)) * 25);
+    return cc * d->B * ((double)(d->H - 2) * (d->W - 2) * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
   }
   if (cin3_padded_ok(d)) return 2.0 * 4 * d->Cout * d->B * Ho * Wo * d->KH * d->KW;   // zero 4th input channel
   return cc * d->B * Ho * Wo * d->KH * d->KW;
@@ -1225,8 +1230,8 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     float* dwc = reinterpret_cast<float*>(ws);
     void* slabs = reinterpret_cast<char*>(ws) + sp.dwc_bytes;
     WgradParams f = p;
-    f.frame = 1;
-    f.M = d->B * (4 * Wo + 4 * (Ho - 4));
+    f.frame = sp.ring;
+    f.M = d->B * (2 * sp.ring * Wo + 2 * sp.ring * (Ho - 2 * sp.ring));
     rc = run_wgrad(f, sp.frame, aligned, dw, db, beta, beta, slabs, st);
     if (rc) return rc;
     if (sp.wino) {
@@ -1234,10 +1239,13 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
       q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);
       q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4); q.dy_bytes = (unsigned)((size_t)d->B * Ho * Wo * d->Cout * 4);
       q.dy_sw = 2 * d->Cout; q.dy_sh = (long long)2 * Wo * d->Cout; q.dy_sb = (long long)Ho * Wo * d->Cout;
-      q.dy_off = ((long long)2 * Wo + 2) * d->Cout; q.dy_prow = (long long)Wo * d->Cout; q.dy_pcol = d->Cout;
+      q.dy_off = 0; q.dy_prow = (long long)Wo * d->Cout; q.dy_pcol = d->Cout;
       q.B = d->B; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout;
-      q.reflect = 0; q.xo = 0;                    // interior source pixels i = oh + 1: taps oh .. oh + 2, a VALID gather
-      q.th = (d->H - 2) / 2; q.tw = (d->W - 2) / 2; q.phases = 4;
+      // every source pixel i: output (2i + a, 2j + b) of phase (a, b) against taps i - 1 .. i + 1 of the source with its edge
+      // REPLICATED -- exact for all outputs but the outermost ring (conv_igemm.hip, forward), whose dy the kernel reads as 0
+      // and whose contribution the 25-tap frame launch above has added
+      q.reflect = 2; q.xo = -1; q.ring_mask = 1;
+      q.th = d->H / 2; q.tw = d->W / 2; q.phases = 4;
       rc = munit_wino_wgrad_launch(q, dwc, (long long)d->Cout * 9 * d->Cin, db, 0.0f, 1.0f, slabs, st);
       if (rc) return rc;
     }

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
         if (REFLECT) {
           ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
           iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+        } else if (MODE == 1 && p.edge) {   // replicated edge (phase convolutions of the sub-pixel up-sampling layers)
+          ih = min(max(ih, 0), p.H - 1); iw = min(max(iw, 0), p.W - 1);
         }
       }
       ro[i] = (unsigned)ih < (unsigned)p.H ? (gb * p.H + ih) * p.W * p.xc : -1;
@@ -546,9 +548,11 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
               }
             } else {
               ih = 2 * ty + p.xo + i; iw = 2 * tx + p.xo + i;
-              if (p.reflect) {
+              if (p.reflect == 1) {
                 ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
                 iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
+              } else if (p.reflect == 2) {   // replicated edge
+                ih = min(max(ih, 0), p.H - 1); iw = min(max(iw, 0), p.W - 1);
               }
             }
             if constexpr (FAST) {
@@ -589,10 +593,19 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
               }
           } else {
             const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
-            g[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
-            g[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
-            g[2][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
-            g[3][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
+            if (p.ring_mask) {   // the outermost ring of the up-sampled output belongs to the frame launch: read it as 0
+              const bool r0 = !((phase >> 1) == 0 && ty == 0), r1 = !((phase >> 1) == 1 && ty == p.th - 1);
+              const bool c0 = !((phase & 1) == 0 && tx == 0), c1 = !((phase & 1) == 1 && tx == p.tw - 1);
+              g[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, r0 && c0 ? ylane : 0x80000000u, y0, 0));
+              g[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, r0 && c1 ? ylane : 0x80000000u, y0 + sw, 0));
+              g[2][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, r1 && c0 ? ylane : 0x80000000u, y0 + sh, 0));
+              g[3][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, r1 && c1 ? ylane : 0x80000000u, y0 + sh + sw, 0));
+            } else {
+              g[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0, 0));
+              g[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sw, 0));
+              g[2][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh, 0));
+              g[3][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, ylane, y0 + sh + sw, 0));
+            }
           }
         }
       } else {

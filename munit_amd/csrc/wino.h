@@ -269,6 +269,7 @@ struct WinoParams {
   int s2, Ho, Wo;      // 1: 4x4 / stride 2 / pad 1 layer forward (F(3x3, 2x2) over four input phases), output extent Ho x Wo;
                        // 2: its backward-data (x = dy of extent H x W, launch phases = parities, dx extent Ho x Wo)
   int mode;            // 0 reflect padding, 1 zero padding, 2 zero padding + border fold (backward-data of a reflect layer)
+  int edge;            // mode 1, 3x3 layers: positions outside the image read the nearest edge pixel instead of 0
   int th, tw;          // 2x2 output tiles per image axis
   int bth, btw;        // 8x8-tile blocks per image axis
   int NB;              // N / 64
@@ -293,7 +294,9 @@ struct WinoWgradParams {
   long long dy_sb, dy_sh, dy_sw, dy_off;   // elements
   long long dy_prow, dy_pcol;              // launch phase ph = 2a + b (gridDim.y) adds a*dy_prow + b*dy_pcol to dy_off
   int B, H, W, Cin, Cout;
-  int reflect;         // padding of x when the patch leaves the image (xo = -1): reflect, else zeros
+  int reflect;         // padding of x when the patch leaves the image (xo = -1): 1 reflect, 2 replicated edge, 0 zeros
+  int ring_mask;       // launch phases = output parities (a, b) of an up-sampling layer: dy row 0 / column 0 of parity 0 and the
+                       // last row / column of parity 1 (the outermost ring of the 2H x 2W output) read as 0
   int xo;              // patch origin: output pixel (oh, ow) reads x rows oh + xo .. oh + xo + 2 (-1: pad 1; 0: VALID)
   int th, tw, tiles;   // 2x2 output tiles per axis of the tiled region, in total
   int cps;             // chunks (of 8 tiles) per split

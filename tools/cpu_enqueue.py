@@ -11,11 +11,6 @@ tr = MUNIT_Trainer(hp); tr.to(dev)
 x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(8, 256))
 def step():
     tr.update_learning_rate(); tr.dis_update(x_a, x_b, hp); tr.gen_update(x_a, x_b, hp, m_a, m_b)
-if len(sys.argv) > 1 and sys.argv[1] == "--graph":       # hipGraph replay instead of eager launches
-    from munit_amd.graph import GraphedStep
-    g = GraphedStep(tr, hp, x_a, x_b, m_a, m_b)
-    def step():
-        g(x_a, x_b, m_a, m_b)
 for _ in range(3): step()
 torch.cuda.synchronize()
 enq = []

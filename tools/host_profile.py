@@ -1,13 +1,16 @@
-"""Where does the HOST time of one step go?  cProfile over 3 steps on the GPU box (python tools/host_profile.py)."""
+"""Where does the HOST spend the enqueue time of a step?  cProfile over a few steps (no device sync inside), top functions by
+own time and by cumulative time.  python tools/host_profile.py [size batch]"""
 import cProfile, os, pstats, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from munit_amd.trainer import MUNIT_Trainer
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
-hp = bench.bench_hp(256, 8)
+hp = bench.bench_hp(size, batch)
 torch.manual_seed(1234)
 tr = MUNIT_Trainer(hp); tr.to(dev)
-x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(8, 256))
+x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(batch, size))
 def step():
     tr.update_learning_rate(); tr.dis_update(x_a, x_b, hp); tr.gen_update(x_a, x_b, hp, m_a, m_b)
 for _ in range(3): step()
@@ -17,6 +20,6 @@ pr.enable()
 for _ in range(3): step()
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
-st.sort_stats("cumulative").print_stats(30)
+for key in ("tottime", "cumulative"):
+    print("==== by", key, "(3 steps)")
+    pstats.Stats(pr).sort_stats(key).print_stats(45)

@@ -14,6 +14,7 @@ channels_last; default initialisation consumes the torch RNG exactly like nn.Con
 nn.Linear so `torch.manual_seed(s)` reproduces the reference's initial weights.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -487,6 +488,10 @@ class AdaINGen_double(nn.Module):
 # --------------------------------------------------------------------------------------
 # discriminator
 # --------------------------------------------------------------------------------------
+# calc_dis_loss runs the fake and the real batch through the discriminator as ONE batch (MUNIT_NO_BATCH_DIS_PAIR=1: two passes)
+BATCH_DIS_PAIR = os.environ.get("MUNIT_NO_BATCH_DIS_PAIR", "0") != "1"
+
+
 class MsImageDis(nn.Module):
     """networks.py:20-115 (LSGAN branch; nsgan hard-codes .cuda() BCE in the reference and is
     not on the configs' path)."""
@@ -532,10 +537,23 @@ class MsImageDis(nn.Module):
         return outputs
 
     def calc_dis_loss(self, input_fake, input_real):
-        outs0 = self.forward(input_fake)
-        outs1 = self.forward(input_real)
         assert self.gan_type == "lsgan", "Unsupported GAN type: {}".format(self.gan_type)
         terms = []
+        if BATCH_DIS_PAIR and input_fake.shape == input_real.shape and input_fake.dtype == input_real.dtype:
+            # one pass over [fake; real]: every layer of the discriminator is per-sample (no batch statistics), so the two
+            # halves of each output are exactly the reference's outs0 / outs1 (networks.py:84-91) -- half the launches, and the
+            # small scales (16x16 ... 4x4 maps), which cannot fill the chip at B = 8, cost about the same at 2 B
+            nb = input_fake.shape[0]
+            n0 = len(ops.MASK_SINK) if ops.MASK_SINK is not None else 0
+            outs = self.forward(torch.cat([ops.nhwc(input_fake), ops.nhwc(input_real)], 0))
+            if ops.MASK_SINK is not None:   # parity harness: hand the recorded LeakyReLU branches over in the reference's order
+                rec = ops.MASK_SINK[n0:]    # (all layers of the fake pass, then all layers of the real pass)
+                ops.MASK_SINK[n0:] = [m[:nb] for m in rec] + [m[nb:] for m in rec]
+            for out in outs:
+                terms += [ops.mse_const(out[:nb], 0.0), ops.mse_const(out[nb:], 1.0)]
+            return ops.scalar_sum(terms)
+        outs0 = self.forward(input_fake)
+        outs1 = self.forward(input_real)
         for out0, out1 in zip(outs0, outs1):
             terms += [ops.mse_const(out0, 0.0), ops.mse_const(out1, 1.0)]
         return ops.scalar_sum(terms)

@@ -740,7 +740,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
       if (p.frame) {
         // frame enumeration (the 2-pixel border of the sub-pixel form): rows are not a raster walk, decode the next one
         const int mn = m + BS_WP;
-        decode_pixel(mn < p.M ? mn : 0, p.Ho, p.Wo, 1, px_b[i], px_oh[i], px_ow[i]);
+        decode_pixel(mn < p.M ? mn : 0, p.Ho, p.Wo, p.frame, px_b[i], px_oh[i], px_ow[i]);
         dp_off[i] = px_b[i] * (int)p.dy_sb + px_oh[i] * (int)p.dy_sh + px_ow[i] * p.dy_sw + (int)p.dy_off + d_col;
         continue;
       }

@@ -43,16 +43,17 @@ inline int pick_split(int B, int HW) {
 // partial[b][split][2][C] : sum(x - pivot), sum((x - pivot)^2), pivot = x[b][0][c]
 template <typename T>
 __global__ __launch_bounds__(NT) void in_stats_kernel(const T* __restrict__ x, double* __restrict__ partial,
-                                                      int HW, int C, int nsplit) {
+                                                      int HW, int C, int nsplit, int CS) {
   extern __shared__ double smd[];  // [PL][QB*4][2]
   double* sm = smd;
-  const Lay L = make_lay(C);
-  const int b = blockIdx.y, sp = blockIdx.x;
+  // blockIdx.z = channel slice of CS channels (CS = C: one slice, the block walks all channel quads)
+  const Lay L = make_lay(CS);
+  const int b = blockIdx.y, sp = blockIdx.x, q0 = blockIdx.z * (CS >> 2);
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const T* xb = x + (long long)b * HW * C;
-  for (int qq = q; qq < L.CQ; qq += L.QB) {
+  for (int qq = q0 + q; qq < q0 + L.CQ; qq += L.QB) {
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
       const f32x4 piv = ld4(xb + qq * 4);
@@ -182,16 +183,16 @@ template <typename T>
 __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ stats, double* __restrict__ partial,
                                                           int HW, int C, int nsplit, const float* __restrict__ adain,
-                                                          int ad_ld, int w_off, int b_off, int relu) {
+                                                          int ad_ld, int w_off, int b_off, int relu, int CS) {
   extern __shared__ double smd[];
   double* sm = smd;
-  const Lay L = make_lay(C);
-  const int b = blockIdx.y, sp = blockIdx.x;
+  const Lay L = make_lay(CS);   // blockIdx.z = channel slice (see in_stats_kernel)
+  const int b = blockIdx.y, sp = blockIdx.x, q0 = blockIdx.z * (CS >> 2);
   const int q = threadIdx.x % L.QB, pl = threadIdx.x / L.QB;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = sp * per, p1 = min(HW, p0 + per);
   const long long base = (long long)b * HW * C;
-  for (int qq = q; qq < L.CQ; qq += L.QB) {
+  for (int qq = q0 + q; qq < q0 + L.CQ; qq += L.QB) {
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (pl < L.PL) {
       f32x4 mean, rstd, w, bb;
@@ -300,6 +301,145 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ 
     }
     const f32x4 r = rstd * w * (g - a1 - xh * a2);
     st4(dx + base + i * 4, r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Channel-sliced form (C a multiple of 64): a block = (pixel split, sample, slice of 64 channels).  Statistics and apply use
+// the same grid, nsplit x B x C/64 with nsplit * C/64 ~ 64, so an apply block needs the statistics of only ITS 64 channels
+// and folds their nsplit partial rows itself (nsplit * 1 KiB from L2, a few per cent of the bytes it streams): the separate
+// fold launch between the two -- 7 us of latency, 200 times per step, on the dependent chain conv -> norm -> conv -- is gone.
+// A pixel's 64-channel slice is 256 contiguous bytes (two full cache lines), a wave's float4 loads cover four of them.
+// ---------------------------------------------------------------------------------------
+constexpr int SLICE = 64;
+
+// sums over the splits of partial[b][split][2][C] for channel c0 + (tid & 63): four groups of threads add every fourth
+// split in order, then the groups are added in order (the order fold_partials uses); valid in threads < 64
+__device__ inline void fold_slice(const double* __restrict__ partial, int b, int C, int nsplit, int c0, double (*red)[SLICE][2],
+                                  double& s1, double& s2) {
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = c0 + cl;
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int k = g; k < nsplit; k += 4) {
+    const double* o = partial + ((long long)(b * nsplit + k) * 2) * C;
+    s1 += o[c];
+    s2 += o[C + c];
+  }
+  if (g > 0) {
+    red[g - 1][cl][0] = s1;
+    red[g - 1][cl][1] = s2;
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      s1 += red[j][cl][0];
+      s2 += red[j][cl][1];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void in_apply_sliced_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             const double* __restrict__ partial, float* __restrict__ stats,
+                                                             int HW, int C, int nsplit, const float* __restrict__ adain,
+                                                             int ad_ld, int w_off, int b_off, float eps,
+                                                             const T* __restrict__ residual, int relu) {
+  __shared__ double red[3][SLICE][2];
+  __shared__ __attribute__((aligned(16))) float scale[SLICE], shift[SLICE];
+  const int b = blockIdx.y, sp = blockIdx.x, c0 = blockIdx.z * SLICE;
+  double s1, s2;
+  fold_slice(partial, b, C, nsplit, c0, red, s1, s2);
+  if (threadIdx.x < SLICE) {   // the arithmetic of in_finalize_kernel
+    const int c = c0 + threadIdx.x;
+    const double inv_n = 1.0 / (double)HW;
+    const double d = s1 * inv_n;
+    const float mean = (float)((double)ld1(x + (long long)b * HW * C + c) + d);   // pivot = first pixel of the plane
+    double var = s2 * inv_n - d * d;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float w = 1.f, bb = 0.f;
+    if (adain != nullptr) {
+      w = adain[(long long)b * ad_ld + w_off + c];
+      bb = adain[(long long)b * ad_ld + b_off + c];
+    }
+    if (sp == 0) {
+      stats[((long long)b * C + c) * 2] = mean;
+      stats[((long long)b * C + c) * 2 + 1] = rstd;
+    }
+    scale[threadIdx.x] = rstd * w;
+    shift[threadIdx.x] = bb - mean * rstd * w;
+  }
+  __syncthreads();
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long base = (long long)b * HW * C + c0;
+  const int q = threadIdx.x & 15;   // quad of the slice: fixed per thread (NT / 16 pixels per sweep)
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+#pragma unroll 4
+  for (int p = p0 + (threadIdx.x >> 4); p < p1; p += NT / 16) {
+    const long long o = base + (long long)p * C + q * 4;
+    f32x4 v = ld4(x + o);
+    v = v * sc + sh;
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (residual != nullptr) v += ld4(residual + o);
+    st4(y + o, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void in_bwd_apply_sliced_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 const double* __restrict__ partial,
+                                                                 const float* __restrict__ stats, T* __restrict__ dx, int HW,
+                                                                 int C, int nsplit, const float* __restrict__ adain,
+                                                                 float* __restrict__ d_adain, int ad_ld, int w_off, int b_off,
+                                                                 int relu) {
+  __shared__ double red[3][SLICE][2];
+  __shared__ __attribute__((aligned(16))) float s_co[6][SLICE];   // mean, rstd, w, b, mean(g), mean(g*xhat)
+  const int b = blockIdx.y, sp = blockIdx.x, c0 = blockIdx.z * SLICE;
+  double a1, a2;
+  fold_slice(partial, b, C, nsplit, c0, red, a1, a2);
+  if (threadIdx.x < SLICE) {   // the arithmetic of in_bwd_finalize_kernel
+    const int c = c0 + threadIdx.x;
+    if (d_adain != nullptr && sp == 0) {
+      d_adain[(long long)b * ad_ld + w_off + c] = (float)a2;
+      d_adain[(long long)b * ad_ld + b_off + c] = (float)a1;
+    }
+    const double inv_n = 1.0 / (double)HW;
+    s_co[0][threadIdx.x] = stats[((long long)b * C + c) * 2];
+    s_co[1][threadIdx.x] = stats[((long long)b * C + c) * 2 + 1];
+    s_co[2][threadIdx.x] = adain ? adain[(long long)b * ad_ld + w_off + c] : 1.f;
+    s_co[3][threadIdx.x] = adain ? adain[(long long)b * ad_ld + b_off + c] : 0.f;
+    s_co[4][threadIdx.x] = (float)(a1 * inv_n);
+    s_co[5][threadIdx.x] = (float)(a2 * inv_n);
+  }
+  __syncthreads();
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = sp * per, p1 = min(HW, p0 + per);
+  const long long base = (long long)b * HW * C + c0;
+  const int q = threadIdx.x & 15;
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(&s_co[0][q * 4]);
+  const f32x4 rstd = *reinterpret_cast<const f32x4*>(&s_co[1][q * 4]);
+  const f32x4 w = *reinterpret_cast<const f32x4*>(&s_co[2][q * 4]);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(&s_co[3][q * 4]);
+  const f32x4 a1v = *reinterpret_cast<const f32x4*>(&s_co[4][q * 4]);
+  const f32x4 a2v = *reinterpret_cast<const f32x4*>(&s_co[5][q * 4]);
+#pragma unroll 4
+  for (int p = p0 + (threadIdx.x >> 4); p < p1; p += NT / 16) {
+    const long long o = base + (long long)p * C + q * 4;
+    const f32x4 xv = ld4(x + o);
+    const f32x4 xh = (xv - mean) * rstd;
+    f32x4 g = ld4(dy + o);
+    if (relu) {   // the forward's own x * scale + shift (see in_bwd_stats_kernel)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 r = rstd * w * (g - a1v - xh * a2v);
+    st4(dx + o, r);
   }
 }
 
@@ -536,6 +676,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_param_kernel(const double* __restri
 
 namespace {
 size_t in_partial_bytes(int B, int C) { return align_up((size_t)B * MAX_SPLIT * 2 * C * sizeof(double), 256); }
+bool in_sliced(int C) { return C % SLICE == 0 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SLICED_NORM"); }
+// pixel splits of the sliced grid: pick_split's block count shared out over the C / 64 slices
+int sliced_split(int B, int HW, int C) { return std::max(1, pick_split(B, HW) / (C / SLICE)); }
 }
 // [split partials (fp64)][per-(sample, channel) coefficients of the apply kernels: 6 floats]
 extern "C" size_t munit_instnorm_workspace_bytes(int B, int HW, int C) {
@@ -554,11 +697,22 @@ int instnorm_fwd_t(const T* x, T* y, float* stats, int B, int HW, int C, const f
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int ns = pick_split(B, HW);
   double* partial = reinterpret_cast<double*>(ws);
+  if (in_sliced(C)) {
+    const int ns = sliced_split(B, HW, C);
+    const Lay Ls = make_lay(SLICE);
+    hipLaunchKernelGGL(in_stats_kernel<T>, dim3(ns, B, C / SLICE), dim3(NT), (size_t)Ls.PL * Ls.QB * 8 * sizeof(double), st, x,
+                       partial, HW, C, ns, SLICE);
+    MUNIT_CHECK_LAUNCH("in_stats");
+    hipLaunchKernelGGL(in_apply_sliced_kernel<T>, dim3(ns, B, C / SLICE), dim3(NT), 0, st, x, y, partial, stats, HW, C, ns, adain,
+                       ad_ld, w_off, b_off, eps, residual, relu);
+    MUNIT_CHECK_LAUNCH("in_apply_sliced");
+    return MUNIT_OK;
+  }
+  const int ns = pick_split(B, HW);
   const Lay L = make_lay(C);
   hipLaunchKernelGGL(in_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
-                     partial, HW, C, ns);
+                     partial, HW, C, ns, C);
   MUNIT_CHECK_LAUNCH("in_stats");
   float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
   hipLaunchKernelGGL(in_finalize_kernel<T>, dim3(cdiv(C, 64), B), dim3(NT), 0, st, x, partial, stats, coef, B,
@@ -581,11 +735,22 @@ int instnorm_bwd_t(const T* x, const T* dy, const float* stats, T* dx, int B, in
     return MUNIT_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int ns = pick_split(B, HW);
   double* partial = reinterpret_cast<double*>(ws);
+  if (in_sliced(C)) {
+    const int ns = sliced_split(B, HW, C);
+    const Lay Ls = make_lay(SLICE);
+    hipLaunchKernelGGL(in_bwd_stats_kernel<T>, dim3(ns, B, C / SLICE), dim3(NT), (size_t)Ls.PL * Ls.QB * 8 * sizeof(double), st, x,
+                       dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu, SLICE);
+    MUNIT_CHECK_LAUNCH("in_bwd_stats");
+    hipLaunchKernelGGL(in_bwd_apply_sliced_kernel<T>, dim3(ns, B, C / SLICE), dim3(NT), 0, st, x, dy, partial, stats, dx, HW, C, ns,
+                       adain, d_adain, ad_ld, w_off, b_off, relu);
+    MUNIT_CHECK_LAUNCH("in_bwd_apply_sliced");
+    return MUNIT_OK;
+  }
+  const int ns = pick_split(B, HW);
   const Lay L = make_lay(C);
   hipLaunchKernelGGL(in_bwd_stats_kernel<T>, dim3(ns, B), dim3(NT), (size_t)L.PL * L.QB * 8 * sizeof(double), st, x,
-                     dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu);
+                     dy, stats, partial, HW, C, ns, adain, ad_ld, w_off, b_off, relu, C);
   MUNIT_CHECK_LAUNCH("in_bwd_stats");
   float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + in_partial_bytes(B, C));
   hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(cdiv(C, 64), B), dim3(NT), 0, st, partial, stats, coef, B, HW,

@@ -1155,17 +1155,17 @@ extern "C" const char* munit_conv2d_kernel_name(const munit_conv_desc* d, int pa
   // (the second template argument mirrors the FAST decision of munit_wino_wgrad_launch)
   if (wino_s2_wgrad_layer(d)) {
     const bool fast = s2_tiles(d) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT && d->H % 6 == 0 && d->W % 6 == 0 && Ho % 3 == 0 && Wo % 3 == 0;
-    return fast ? "conv_wino_wgrad_kernel<true, true> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<true, false> + wino_wgrad_reduce_kernel";
+    return fast ? "conv_wino_wgrad_kernel<true, true, false> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<true, false, false> + wino_wgrad_reduce_kernel";
   }
   if (wino_wgrad_layer(d)) {
     const bool fast = ((long long)d->B * (d->H / 2) * (d->W / 2)) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT;
-    return fast ? "conv_wino_wgrad_kernel<false, true> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<false, false> + wino_wgrad_reduce_kernel";
+    return fast ? "conv_wino_wgrad_kernel<false, true, false> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<false, false, false> + wino_wgrad_reduce_kernel";
   }
   if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return "conv_lanes_wgrad_kernel";
   if (subpixel_wgrad_ok(d)) {
     SubpixelPlan sp;
     plan_subpixel(d, &sp);
-    return sp.wino ? "conv_wino_wgrad_kernel<false, .> x4 sub-pixel phases + frame + reduce" : "conv_wgrad_kernel x4 sub-pixel phases + frame";
+    return sp.wino ? "conv_wino_wgrad_kernel<false, ., true> x4 sub-pixel phases + frame + reduce" : "conv_wgrad_kernel x4 sub-pixel phases + frame";
   }
   if (cin3_padded_ok(d)) return "conv_wgrad_kernel (3 input channels padded to 4)";
   return "conv_wgrad_kernel + slab_reduce_kernel";

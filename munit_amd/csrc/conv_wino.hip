@@ -485,7 +485,9 @@ constexpr int WG_BUF = 16 * WG_PLANE;       // floats per operand buffer (32 KiB
 // not hidden behind v_mfma_f32_16x16x4_f32 of the partner wave (tools/ubench/mfma_coissue.hip: additive), so they are what the
 // kernel's distance from the matrix roofline consists of.  FAST (host-checked: every tile of every chunk exists and every patch
 // position is inside the image after reflection) drops the per-load validity branches and the zero fills.
-template <bool S2, bool FAST>
+// RING: phase gradients of an up-sampling layer (p.reflect == 2, p.ring_mask): replicated source edge, the outermost ring of dy
+// read as 0.  A template argument, not a run-time branch: the uniform tests alone cost the 3x3 trunk layers 6 % (208 -> 221 us).
+template <bool S2, bool FAST, bool RING = false>
 __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * WG_BUF];   // E0 E1 V0 V1
   const int tid = threadIdx.x, lane = tid & 63;
@@ -548,11 +550,11 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
               }
             } else {
               ih = 2 * ty + p.xo + i; iw = 2 * tx + p.xo + i;
-              if (p.reflect == 1) {
+              if constexpr (RING) {   // replicated edge
+                ih = min(max(ih, 0), p.H - 1); iw = min(max(iw, 0), p.W - 1);
+              } else if (p.reflect) {
                 ih = ih < 0 ? -ih : (ih >= p.H ? 2 * p.H - 2 - ih : ih);
                 iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
-              } else if (p.reflect == 2) {   // replicated edge
-                ih = min(max(ih, 0), p.H - 1); iw = min(max(iw, 0), p.W - 1);
               }
             }
             if constexpr (FAST) {
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
               }
           } else {
             const int y0 = (int)(p.dy_off + (phase >> 1) * p.dy_prow + (phase & 1) * p.dy_pcol + b * p.dy_sb) * 4 + 2 * ty * sh + 2 * tx * sw;
-            if (p.ring_mask) {   // the outermost ring of the up-sampled output belongs to the frame launch: read it as 0
+            if constexpr (RING) {   // the outermost ring of the up-sampled output belongs to the frame launch: read it as 0
               const bool r0 = !((phase >> 1) == 0 && ty == 0), r1 = !((phase >> 1) == 1 && ty == p.th - 1);
               const bool c0 = !((phase & 1) == 0 && tx == 0), c1 = !((phase & 1) == 1 && tx == p.tw - 1);
               g[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yres, r0 && c0 ? ylane : 0x80000000u, y0, 0));
@@ -878,7 +880,12 @@ int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, fl
   if (p.s2) {
     if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, true>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, false>), grid, dim3(512), 0, st, p);
+  } else if (p.ring_mask) {
+    MUNIT_CHECK_ARG(p.reflect == 2 && p.xo == -1 && p.phases == 4, "conv_wino_wgrad: ring_mask goes with the replicated edge and 4 phases");
+    if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, true, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, false, true>), grid, dim3(512), 0, st, p);
   } else {
+    MUNIT_CHECK_ARG(p.reflect != 2, "conv_wino_wgrad: the replicated edge goes with ring_mask");
     if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, true>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<false, false>), grid, dim3(512), 0, st, p);
   }

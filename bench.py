@@ -113,8 +113,24 @@ class PmcSummary:
         return None
 
 
+def cpu_quota():
+    """CPUs the cgroup grants this process (None: unlimited).  The GPU boxes show 256 logical CPUs and grant 16."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else max(1, -(-int(quota) // int(period)))
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
-    """Physical cores of one socket (the CPU-baseline thread count SURVEY.md section 8d asks for)."""
+    """Threads of the CPU baseline: the physical cores of one socket, capped by what the cgroup
+    lets the process use -- more threads than the quota only get throttled."""
+    q = cpu_quota()
+    n = _socket_cores()
+    return n if q is None else max(1, min(n, q))
+
+
+def _socket_cores():
     try:
         seen = set()
         phys = core = None
@@ -171,7 +187,7 @@ def cpu_baseline(size, seconds_budget=45.0):
     finally:
         torch.set_num_threads(prev)
     return {"value": round(v, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle/munit_oracle.py (torch %s CPU fp32, %d threads = physical cores of one socket), %dx%d batch "
+            "sample": "oracle/munit_oracle.py (torch %s CPU fp32, %d threads = physical cores of one socket capped by the cgroup CPU quota), %dx%d batch "
                       "1, 1 warm-up + %d timed dis_update+gen_update steps" % (torch.__version__, cores, size, size, n),
             "config0_128x128_b1": {"value": round(v128, 4), "unit": "images/s", "timed_steps": n128}}
 

@@ -8,8 +8,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs and grant 16; torch's default of one thread per visible core then spends the quota in a fraction of every scheduling
+    period and the fp64 oracle runs 2-3x slower, erratically)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(usable_cpus())      # the oracle (CPU, fp64) is where the suite's time goes
 
 
 # Collection order of the GPU suite: the fp32 hot path first (op parity, step parity, BASELINE-shape parity), then the

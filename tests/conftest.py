@@ -38,7 +38,7 @@ def pytest_configure(config):
 # "next" rows (data pipeline, data parallel), the opt-in arithmetic modes last -- `pytest -x` (the driver's form) then reaches
 # every core parity test before anything optional can stop the run.
 _ORDER = ["test_gpu_ops", "test_gpu_step", "test_gpu_shapes", "test_gpu_data", "test_gpu_dp", "test_gpu_bf16s",
-          "test_gpu_bf16", "test_gpu_f32x3"]
+          "test_gpu_bf16", "test_gpu_f32x3", "test_gpu_hd_step"]
 
 
 def pytest_collection_modifyitems(session, config, items):

@@ -166,13 +166,14 @@ def test_l1_bf16_storage():
     assert ad.grad.dtype == BF and nerr(ad.grad, g) <= BF16_OUT and nerr(bd.grad, -g) <= BF16_OUT
 
 
-def test_step_bf16_storage_tracks_fp32_step():
+@pytest.mark.parametrize("size,batch", [(64, 2), (256, 32)], ids=["64_b2", "config3_256_b32"])
+def test_step_bf16_storage_tracks_fp32_step(size, batch):
     """One dis_update + gen_update with bf16 storage against the same step in fp32 (same weights, same batch): every
-    loss within the mode's stated 2e-2; the activations of the trunk are bf16, the images fp32."""
+    loss within the mode's stated 2e-2; the activations of the trunk are bf16, the images fp32.  The second case is
+    BASELINE.json config #3 at its own size (256x256, batch 32)."""
     from munit_amd import ops
     from munit_amd.trainer import MUNIT_Trainer
     import bench
-    size, batch = 64, 2
     x_a, x_b, m_a, m_b = (t.to(dev()) for t in bench.make_batch(batch, size))
     out = {}
     for prec in ("f32", "bf16s"):

@@ -14,10 +14,11 @@ small-shape op tests (2e-5 forward, 1e-4 gradients, normalised max error):
       4x4 s2 256->512 @32 lrelu      discriminator last layer (split-K implicit GEMM)
       IN / AdaIN / LayerNorm at their real extents (scripts/networks.py:657, 823-845, 862-878)
   config #4  512x512, batch 4, fp32  (configs/config_HD.yaml:73-75)
-      3x3 256->256 @128x128 (B=4), up x2 + 5x5 128->64 @256->512 (B=2: 20 s of fp64 reference per sample)
+      3x3 256->256 @128x128 (B=4), up x2 + 5x5 128->64 @256->512 (B=4)
   config #3  256x256, batch 32, bf16 storage (build extension)
       3x3 256->256 @64x64 on bf16 tensors, vs fp64 on the same bf16-valued operands
-  and ONE whole dis_update + gen_update at 256x256 (batch 1) against the fp64 oracle (tests/parity.py).
+  and ONE whole dis_update + gen_update at 256x256 (batch 1) against the fp64 oracle (tests/parity.py); the same at 512x512
+  is tests/test_gpu_hd_step.py (two minutes of oracle: collected last).
 
 The fp64 reference convolutions cost seconds each on the host (torch CPU fp64: ~10-60 GMAC/s); the file as a whole a few minutes."""
 import pytest
@@ -54,8 +55,7 @@ LAYERS = [
     ("cfg2_dis_first", 3, 64, 4, 2, 1, 0, "lrelu", 8, 256, 256),
     ("cfg2_dis_last", 256, 512, 4, 2, 1, 0, "lrelu", 8, 32, 32),
     ("cfg4_trunk3x3", 256, 256, 3, 1, 1, 0, "none", 4, 128, 128),
-    ("cfg4_up5x5_128_64", 128, 64, 5, 1, 2, 1, "none", 2, 256, 256),   # half of config #4's batch: the fp64 reference of this one
-                                                                         # layer costs 20 s per sample on the host
+    ("cfg4_up5x5_128_64", 128, 64, 5, 1, 2, 1, "none", 4, 256, 256),
 ]
 
 
@@ -215,7 +215,7 @@ def test_bf16s_trunk_layer_at_config3_batch():
 
 
 def test_step_matches_oracle_at_256():
-    """One dis_update + gen_update at BASELINE.json configs[1]'s resolution (256x256; batch 1 keeps the fp64 oracle to about a
+    """One dis_update + gen_update at BASELINE.json configs[1]'s resolution (256x256; batch 1 keeps the fp64 oracle to about half a
     minute on the host) with the tolerances of the 64x64 step test: losses 1e-5, every gradient tensor <= 5e-5 with the kinks
     pinned AND the recorded branches audited against the oracle's own (tests/parity.py KINK_NOISE), Adam moments, weight step."""
     rep = run_step_parity(size=256, batch=1, gen_state=1, iters=1, device="cuda:0")

@@ -37,8 +37,8 @@ def test_modules_match_golden_forward(golden, gs):
         assert nerr(o, torch.from_numpy(arrays[key + "_dis%d" % i])) <= 1e-4
 
 
-@pytest.mark.parametrize("gs,iters", [(1, 2), (0, 1)])   # the iterations run the fp64 oracle on the host: ~30 s each;
-# two iterations cross the StepLR boundary (step_size 2) and carry Adam moments; tools/parity_report.py runs three
+@pytest.mark.parametrize("gs,iters", [(1, 3), (0, 2)])   # the iterations run the fp64 oracle on the host: ~6 s each;
+# they cross the StepLR boundary (step_size 2) and carry Adam moments
 def test_step_matches_oracle(gs, iters):
     """dis_update + gen_update vs the fp64 oracle: losses 1e-5, EVERY gradient tensor within SURVEY.md 8c's 1e-2
     (ReLU / LeakyReLU branches pinned to the HIP forward, tests/parity.py::GradCheck), Adam moments, weight step."""
@@ -210,16 +210,18 @@ def test_sample_and_sample_fid_match_oracle(guided):
         assert tr.training and nerr(fid, x_ab1) <= 1e-4
 
 
-def test_full_size_step_is_bitwise_reproducible():
-    """BASELINE configs[1] at full size (256x256, batch 8, three streams): two fresh trainers run two
-    update_learning_rate + dis_update + gen_update steps each and must end with bit-identical weights, Adam moments and
-    losses -- the size-independent property that covers the split-K slab reductions, the side-stream accumulation order
-    into the flat gradient and the prepared weight images at the shapes the metric is quoted on."""
+@pytest.mark.parametrize("size,batch", [(256, 8), (512, 4)], ids=["config2_256_b8", "config4_512_b4"])
+def test_full_size_step_is_bitwise_reproducible(size, batch):
+    """BASELINE configs[1] (256x256, batch 8) and config #4 (config_HD.yaml: 512x512, batch 4) at full size, three streams:
+    two fresh trainers run two update_learning_rate + dis_update + gen_update steps each and must end with bit-identical
+    weights, Adam moments and losses -- the size-independent property that covers the split-K slab reductions, the
+    side-stream accumulation order into the flat gradient and the prepared weight images at the shapes the metric is
+    quoted on."""
     import bench
     from munit_amd.trainer import MUNIT_Trainer
     dev = torch.device("cuda:0")
-    hp = bench.bench_hp(256, 8)
-    x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(8, 256))
+    hp = bench.bench_hp(size, batch)
+    x_a, x_b, m_a, m_b = (t.to(dev) for t in bench.make_batch(batch, size))
 
     def run():
         torch.manual_seed(1234)
@@ -239,6 +241,43 @@ def test_full_size_step_is_bitwise_reproducible():
     a, b = run(), run()
     for u, v in zip(a, b):
         assert torch.isfinite(u).all() and torch.equal(u, v)
+
+
+def test_hd_batch_gradient_is_the_mean_of_the_per_sample_gradients():
+    """BASELINE config #4 at its own size (512x512, batch 4), where the fp64 oracle is out of reach of a test: every loss
+    of the step is a batch mean and every normalisation is per sample, so the flat gradients of a
+    batch-4 dis_update / gen_update must equal the mean of the four batch-1 gradients on the same weights -- a
+    size-independent property that a kernel mixing samples, or mis-tiling the larger batch, cannot satisfy."""
+    import bench
+    from munit_amd.trainer import MUNIT_Trainer
+    from tests.parity import l2err
+    dev = torch.device("cuda:0")
+    size, batch = 512, 4
+    data = bench.make_batch(batch, size)
+
+    def grads(sel):
+        hp = bench.bench_hp(size, len(sel))
+        torch.manual_seed(1234)
+        tr = MUNIT_Trainer(hp)
+        tr.to(dev)
+        x_a, x_b, m_a, m_b = (t[sel].to(dev) for t in data)
+        tr.update_learning_rate()
+        d0 = tr.dis_opt.flat_p.detach().clone()
+        tr.dis_update(x_a, x_b, hp)
+        g_dis = tr.dis_opt.flat_g.detach().double().clone()
+        with torch.no_grad():      # gen_update on the INITIAL discriminator in every run: undo the Adam step just taken
+            tr.dis_opt.flat_p.copy_(d0)
+        tr.gen_update(x_a, x_b, hp, m_a, m_b)
+        g_gen = tr.gen_opt.flat_g.detach().double().clone()
+        torch.cuda.synchronize()
+        return g_dis, g_gen
+
+    whole = grads(list(range(batch)))
+    parts = [grads([i]) for i in range(batch)]
+    for k, bound in ((0, 1e-4), (1, 2e-3)):       # bounds of the two-rank test (tests/test_gpu_dp.py)
+        mean = sum(p[k] for p in parts) / batch
+        assert torch.isfinite(whole[k]).all()
+        assert l2err(whole[k], mean) <= bound, (k, l2err(whole[k], mean))
 
 
 def test_checkpoint_roundtrip_on_device(tmp_path):

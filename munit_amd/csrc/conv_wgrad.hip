@@ -669,10 +669,15 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
 constexpr int BS_WP = 64;        // pixels per step
 __device__ const float munit_wgrad_zero16b[4] = {0.f, 0.f, 0.f, 0.f};
 
-__global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p) {
-  constexpr int BC = 128, WKT = 128, WC = 64, WK = 32, MT = 4, NT = 2;
+// TC = 2: tile 256 (cout) x 256 (k), one block per CU.  At the bf16 matrix rate the 128 x 128 tile is bound by what the L2
+// delivers (32 KiB per 2.1 MFLOP step: the trunk layer at B = 32 moved 2.4 GB per launch through the L2 at 6.8 TB/s, 0.18 of the
+// matrix peak); the larger tile halves the bytes per FLOP.  Images stay 32 pixels x 128 channels: a stage holds, per operand and
+// 32-pixel group, TC of them side by side.
+template <int TC>
+__global__ __launch_bounds__(WTHR, TC == 1 ? 4 : 2) void conv_wgrad_bf16s_kernel(WgradParams p) {
+  constexpr int BC = 128 * TC, WKT = 128 * TC, WC = 64 * TC, WK = 32 * TC, MT = 4 * TC, NT = 2 * TC;
   constexpr int IMG = 8192;                 // one 32-pixel x 128-channel bf16 image
-  constexpr int STAGE = 4 * IMG;            // dy images 0,1 then x images 0,1
+  constexpr int STAGE = 4 * TC * IMG;       // image ((operand * 2 + pixel group) * TC + channel half): dy first, then x
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * DMA_MAX_HW];
   int* const offtab = reinterpret_cast<int*>(smem + 2 * STAGE);
 
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
   const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
   const bf16_t* __restrict__ dyg = reinterpret_cast<const bf16_t*>(p.dy);
 
-  // the filter tap and first input channel of this block's 128 k-columns
+  // the filter tap and first input channel of this block's k-columns (Cin % WKT == 0: one tap per block)
   const int tap = kc0 / p.Cin, ci0 = kc0 - tap * p.Cin;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   constexpr int OFF_NONE = -(1 << 30);
@@ -702,9 +707,8 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
   // the image keeps global chunk c of row r at position c ^ f(r), so this lane fetches chunk pos ^ f(r)
   const int r = tid >> 4, pos = tid & 15;
   const int chunk = pos ^ (((r & 3) << 2) | ((r >> 2) & 3));
-  const int x_col = ci0 + 8 * chunk;                       // channel of x
-  const int d_col = co0 + 8 * chunk;                       // channel of dy
-  const bool d_ok = d_col < p.Cout;
+  const int x_col = ci0 + 8 * chunk;                       // channel of x   (+ 128 per channel half)
+  const int d_col = co0 + 8 * chunk;                       // channel of dy  (+ 128 per channel half)
   int px_b[2], px_oh[2], px_ow[2], dp_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -730,13 +734,16 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
       const int m = mbase + 32 * i + r;
       const bool mok = m < m_end;
       const int xo = px_b[i] * hwc + offtab[px_oh[i]] + offtab[p.Ho + px_ow[i]] + x_col;
-      const void* gx = (mok && xo >= 0) ? (const void*)(xg + xo) : (const void*)munit_wgrad_zero16b;
-      const void* gd = (mok && d_ok) ? (const void*)(dyg + dp_off[i]) : (const void*)munit_wgrad_zero16b;
-      // wave w lands rows 4w .. 4w+3 of the image: 1 KiB per wave instruction, lane l at base + 16 l
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gd,
-                                       (__attribute__((address_space(3))) void*)(sb + i * IMG + 1024 * w), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
-                                       (__attribute__((address_space(3))) void*)(sb + (2 + i) * IMG + 1024 * w), 16, 0, 0);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        const void* gx = (mok && xo >= 0) ? (const void*)(xg + xo + 128 * c) : (const void*)munit_wgrad_zero16b;
+        const void* gd = (mok && d_col + 128 * c < p.Cout) ? (const void*)(dyg + dp_off[i] + 128 * c) : (const void*)munit_wgrad_zero16b;
+        // wave w lands rows 4w .. 4w+3 of the image: 1 KiB per wave instruction, lane l at base + 16 l
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gd,
+                                         (__attribute__((address_space(3))) void*)(sb + (i * TC + c) * IMG + 1024 * w), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gx,
+                                         (__attribute__((address_space(3))) void*)(sb + ((2 + i) * TC + c) * IMG + 1024 * w), 16, 0, 0);
+      }
       if (p.frame) {
         // frame enumeration (the 2-pixel border of the sub-pixel form): rows are not a raster walk, decode the next one
         const int mn = m + BS_WP;
@@ -769,9 +776,10 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
   const int fj = lane & 15, fg = lane >> 4;
   // operand of the 16-channel tile starting at channel c0: pixels 8 fg .. 8 fg + 7 of channel c0 + fj (see tr_frag of
   // conv_wgrad_kernel: two transposed 4 x 16 block reads)
-  auto tr_frag = [&](const char* im, int c0) -> bf16x8 {
+  auto tr_frag = [&](const char* im0, int c0) -> bf16x8 {   // im0: first of the TC images of (operand, pixel group)
     const int q = fj >> 2, pp = lane & 3;
-    const int ch = (c0 >> 3) + (pp >> 1);
+    const char* im = im0 + (c0 >> 7) * IMG;
+    const int ch = ((c0 & 127) >> 3) + (pp >> 1);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (s16x4 __attribute__((address_space(3)))*)(im + img_off(8 * fg + q, ch) + 8 * (pp & 1)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -791,10 +799,10 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
     for (int h = 0; h < 2; ++h) {          // the two 32-pixel images of the stage: one MFMA contracts a whole image
       bf16x8 hb[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) hb[u] = tr_frag(sb + (2 + h) * IMG, wn * WK + 16 * u);
+      for (int u = 0; u < NT; ++u) hb[u] = tr_frag(sb + (2 + h) * TC * IMG, wn * WK + 16 * u);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const bf16x8 ha = tr_frag(sb + h * IMG, wm * WC + 16 * t);
+        const bf16x8 ha = tr_frag(sb + h * TC * IMG, wm * WC + 16 * t);
 #pragma unroll
         for (int u = 0; u < NT; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb[u], acc[t][u], 0, 0, 0);
@@ -803,7 +811,8 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_bf16s_kernel(WgradParams p
     if (do_bias && tid < BC) {
 #pragma unroll 8
       for (int rr = 0; rr < BS_WP; ++rr)
-        bsum += (float)*reinterpret_cast<const bf16_t*>(sb + (rr >> 5) * IMG + img_off(rr & 31, tid >> 3) + 2 * (tid & 7));
+        bsum += (float)*reinterpret_cast<const bf16_t*>(sb + ((rr >> 5) * TC + (tid >> 7)) * IMG + img_off(rr & 31, (tid & 127) >> 3) +
+                                                       2 * (tid & 7));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -945,15 +954,16 @@ struct WgradPlan {
 };
 
 // split-K plan of one launch: M pixels reduced, Cout x Ktot outputs
-void plan_launch(int M, int Ktot, int Cout, bool aligned, WgradPlan* pl) {
-  pl->bc = Cout <= 64 ? 64 : 128;
+// big256: the bf16-storage kernel's 256 x 256 tile (conv_wgrad_bf16s_kernel<2>, one block per CU)
+void plan_launch(int M, int Ktot, int Cout, bool aligned, WgradPlan* pl, bool big256 = false) {
+  pl->bc = big256 ? 256 : (Cout <= 64 ? 64 : 128);
   pl->k_tiles = cdiv(Ktot, pl->bc == 128 ? 128 : 256);
   pl->c_tiles = cdiv(Cout, pl->bc);
   const int tiles = pl->k_tiles * pl->c_tiles;
   // One full round of resident blocks: 256 CUs x blocks/CU the register budget admits.  A grid of e.g.
   // 1025 equal blocks on 1024 slots costs two rounds, so the split count is floored to fit one round;
   // at least 128 pixels per split, at most 512 splits.
-  const int slots = 256 * wgrad_blocks_per_cu(pl->bc, aligned);
+  const int slots = big256 ? 256 : 256 * wgrad_blocks_per_cu(pl->bc, aligned);
   int want = std::max(1, slots / tiles);
   int max_by_pix = std::max(1, M / 128);
   int ns = std::max(1, std::min(std::min(want, max_by_pix), 512));
@@ -991,11 +1001,17 @@ int run_wgrad(WgradParams p, const WgradPlan& pl, bool aligned, float* dw, float
     if (p.x_bf16 && p.dy_bf16 && p.Cin % 128 == 0 && p.Cout % 8 == 0 && p.Ho + p.Wo <= DMA_MAX_HW &&
         !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA")) {
       // direct-to-LDS bf16 kernel: 128 x 128 tiles (Cout padded), 64-pixel steps; never more splits than the plan's slabs hold
+      // (pl.bc == 256: the plan was made for the 256 x 256 tile, see plan_launch)
       int pps = (cdiv(p.M, pl.nsplit) + BS_WP - 1) / BS_WP * BS_WP;
       p.pix_per_split = pps;
       const int ns = cdiv(p.M, pps);
-      dim3 g2((unsigned)cdiv(p.Ktot, 128), (unsigned)cdiv(p.Cout, 128), (unsigned)ns);
-      hipLaunchKernelGGL(conv_wgrad_bf16s_kernel, g2, dim3(WTHR), 0, st, p);
+      if (pl.bc == 256) {
+        dim3 g2((unsigned)(p.Ktot / 256), (unsigned)(p.Cout / 256), (unsigned)ns);
+        hipLaunchKernelGGL(conv_wgrad_bf16s_kernel<2>, g2, dim3(WTHR), 0, st, p);
+      } else {
+        dim3 g2((unsigned)cdiv(p.Ktot, 128), (unsigned)cdiv(p.Cout, 128), (unsigned)ns);
+        hipLaunchKernelGGL(conv_wgrad_bf16s_kernel<1>, g2, dim3(WTHR), 0, st, p);
+      }
       MUNIT_CHECK_LAUNCH("conv_wgrad_bf16s");
       const long long n = (long long)p.Cout * p.Ktot;
       const int blocks = (int)std::min<long long>((n + p.Cout + 255) / 256, 4096);
@@ -1058,6 +1074,17 @@ void plan_cin3(const munit_conv_desc* d, int Ho, int Wo, Cin3Plan* cp) {
   plan_launch(d->B * Ho * Wo, d->KH * d->KW * 4, d->Cout, true, &cp->pl);
   cp->x4_bytes = align_up((size_t)d->B * d->H * d->W * 4 * sizeof(float), 256);
   cp->dw4_bytes = align_up((size_t)d->Cout * d->KH * d->KW * 4 * sizeof(float), 256);
+}
+
+// bf16-storage layers whose backward-weight takes the 256 x 256 tile: both tensors bf16, whole 256-channel tiles on both sides
+// (one filter tap per block), the direct-to-LDS conditions of run_wgrad, and enough pixels that 256 / tiles splits keep >= 16 steps
+bool bf16s_big_tile(const munit_conv_desc* d, int Ho, int Wo) {
+  if (MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_BIG_TILE") || MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_DMA")) return false;
+  if (d->in_dtype != MUNIT_DTYPE_BF16 || d->out_dtype != MUNIT_DTYPE_BF16) return false;
+  if (d->Cin % 256 != 0 || d->Cout % 256 != 0 || Ho + Wo > DMA_MAX_HW) return false;
+  const long long tiles = (long long)(d->KH * d->KW * d->Cin / 256) * (d->Cout / 256);
+  const long long M = (long long)d->B * Ho * Wo;
+  return tiles <= 256 && M * tiles >= 256ll * 1024;
 }
 
 bool subpixel_wgrad_ok(const munit_conv_desc* d) {
@@ -1126,7 +1153,7 @@ extern "C" size_t munit_conv2d_wgrad_workspace_bytes(const munit_conv_desc* d) {
     return cp.x4_bytes + cp.dw4_bytes + cp.pl.slab_bytes + cp.pl.bias_bytes;
   }
   WgradPlan pl;
-  plan_launch(d->B * Ho * Wo, d->KH * d->KW * d->Cin, d->Cout, d->Cin % 4 == 0, &pl);
+  plan_launch(d->B * Ho * Wo, d->KH * d->KW * d->Cin, d->Cout, d->Cin % 4 == 0, &pl, bf16s_big_tile(d, Ho, Wo));
   return pl.slab_bytes + pl.bias_bytes;
 }
 
@@ -1290,6 +1317,6 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
     return MUNIT_OK;
   }
   WgradPlan pl;
-  plan_launch(p.M, p.Ktot, d->Cout, aligned, &pl);
+  plan_launch(p.M, p.Ktot, d->Cout, aligned, &pl, bf16s_big_tile(d, Ho, Wo));
   return run_wgrad(p, pl, aligned, dw, db, beta, beta, ws, st);
 }

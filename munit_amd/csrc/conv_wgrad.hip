@@ -683,7 +683,16 @@ __global__ __launch_bounds__(WTHR, TC == 1 ? 4 : 2) void conv_wgrad_bf16s_kernel
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int kc0 = blockIdx.x * WKT, co0 = blockIdx.y * BC, split = blockIdx.z;
+  // XCD-aware order: workgroups go to the 8 XCDs round-robin by linear id, so the k / cout tiles of ONE pixel split -- which
+  // read the same dy and x rows -- would fetch them through eight different L2s.  Every XCD gets a contiguous run of logical
+  // blocks instead (tile index fastest), so a split's tiles meet in one L2.
+  int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const int nb = gridDim.x * gridDim.y * gridDim.z, q = nb >> 3, rr = nb & 7, xcd = blk & 7, idx = blk >> 3;
+    blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int bx = blk % gridDim.x, by = (blk / gridDim.x) % gridDim.y, split = blk / (gridDim.x * gridDim.y);
+  const int kc0 = bx * WKT, co0 = by * BC;
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(p.M, m_begin + p.pix_per_split);
   const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(WTHR, TC == 1 ? 4 : 2) void conv_wgrad_bf16s_kernel
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[a][t][e] = 0.f;
   float bsum = 0.f;
-  const bool do_bias = p.bias_slab != nullptr && blockIdx.x == 0;
+  const bool do_bias = p.bias_slab != nullptr && bx == 0;
   const int fj = lane & 15, fg = lane >> 4;
   // operand of the 16-channel tile starting at channel c0: pixels 8 fg .. 8 fg + 7 of channel c0 + fj (see tr_frag of
   // conv_wgrad_kernel: two transposed 4 x 16 block reads)

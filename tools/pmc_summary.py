@@ -29,7 +29,7 @@ out = ["# kernel-source fingerprint: " + bench.lib_fingerprint(),
        "FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); KB -> MB, per launch.",
        "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCD * 1024 SIMD); clock (MHz) = GRBM_GUI_ACTIVE / 8 / duration.",
        "NOTE: the PMC passes run at pinned profiling clocks; the bare run is throttled under matrix load, see DESIGN.md.", ""]
-for k in sorted(f, key=lambda k: -f[k][2])[:18]:
+for k in sorted(f, key=lambda k: -f[k][2])[:int(os.environ.get("PMC_ROWS", "18"))]:
     n, fs, dur = f[k]
     ws, ms, gs = w.get(k, [1, 0, 0]), m.get(k, [1, 0, 0]), g.get(k, [1, 1, 1])
     util = ms[1] / ms[0] / (gs[1] / gs[0] / 8 * 1024) * 100 if gs[1] else 0

@@ -668,6 +668,12 @@ __global__ __launch_bounds__(WTHR, 4) void conv_wgrad_kernel(WgradParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BS_WP = 64;        // pixels per step
 __device__ const float munit_wgrad_zero16b[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef WGB_STAMP   // diagnostic build (tools/wgrad_bf16_stamps.py): shader-clock accounting of the main loop per wave
+__device__ long long g_wgb_stamps[8 * 8 * 4];   // [block < 8][wave][DMA issue, fragments + MFMA issue, vmcnt wait, barrier]
+#define WGB(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); wgb_acc[i] += t_ - wgb_last; wgb_last = t_; } while (0)
+#else
+#define WGB(i) do { } while (0)
+#endif
 
 // TC = 2: tile 256 (cout) x 256 (k), one block per CU.  At the bf16 matrix rate the 128 x 128 tile is bound by what the L2
 // delivers (32 KiB per 2.1 MFLOP step: the trunk layer at B = 32 moved 2.4 GB per launch through the L2 at 6.8 TB/s, 0.18 of the
@@ -800,9 +806,22 @@ __global__ __launch_bounds__(WTHR, TC == 1 ? 4 : 2) void conv_wgrad_bf16s_kernel
   if (m_begin < m_end) dma(m_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef WGB_STAMP
+  long long wgb_acc[4] = {0, 0, 0, 0};
+  long long wgb_last = __builtin_amdgcn_s_memtime();
+#endif
+  // Stamps (tools/wgrad_bf16_stamps.py, L2-warm loop, 256 x 256 tile): issuing the 8 loads of a stage costs a wave ~1 300 of a
+  // step's 4 900 cycles (the CU's address unit takes ~165 cycles per 1 KiB piece when eight waves push at once), the MFMA phase
+  // 2 600-3 300 for 2 x 1 024 cycles of matrix work per SIMD, the final wait 60: the compiler has already put an s_waitcnt
+  // vmcnt(0) in front of the first LDS read after the loads (it cannot tell the stage being filled from the one being read).
+  // Tried on that basis, none kept: staggering the issue between the two waves of a SIMD (-15 % in the warm loop, -2 % inside
+  // the step, where the operands come from HBM), one piece between every two row tiles (+25 %), the loads as inline assembly
+  // outside the compiler's wait bookkeeping (+5 %: its memory clobbers pin the fragment reads), a ring of four 32-pixel
+  // groups (+3 %).
   int cur = 0;
   for (int mb = m_begin; mb < m_end; mb += BS_WP) {
     if (mb + BS_WP < m_end) dma(mb + BS_WP, cur ^ 1);
+    WGB(0);
     const char* sb = smem + cur * STAGE;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {          // the two 32-pixel images of the stage: one MFMA contracts a whole image
@@ -823,10 +842,17 @@ __global__ __launch_bounds__(WTHR, TC == 1 ? 4 : 2) void conv_wgrad_bf16s_kernel
         bsum += (float)*reinterpret_cast<const bf16_t*>(sb + ((rr >> 5) * TC + (tid >> 7)) * IMG + img_off(rr & 31, (tid & 127) >> 3) +
                                                        2 * (tid & 7));
     }
+    WGB(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WGB(2);
     __syncthreads();
+    WGB(3);
     cur ^= 1;
   }
+#ifdef WGB_STAMP
+  if (blk < 8 && lane == 0)
+    for (int i = 0; i < 4; ++i) g_wgb_stamps[(blk * 8 + wave) * 4 + i] = wgb_acc[i];
+#endif
 
   // natural C/D map: accumulator (t, u), register e of lane (fj, fg) = cout row 16 t + 4 fg + e, k column 16 u + fj
   float* out = p.slab + (long long)split * p.Cout * p.Ktot;
@@ -1329,3 +1355,9 @@ extern "C" int munit_conv2d_wgrad(const munit_conv_desc* d, const void* x, const
   plan_launch(p.M, p.Ktot, d->Cout, aligned, &pl, bf16s_big_tile(d, Ho, Wo));
   return run_wgrad(p, pl, aligned, dw, db, beta, beta, ws, st);
 }
+
+#ifdef WGB_STAMP
+extern "C" int munit_debug_wgrad_bf16_stamps(long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wgb_stamps), sizeof(long long) * 8 * 8 * 4) == hipSuccess ? 0 : -1;
+}
+#endif

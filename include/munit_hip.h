@@ -54,6 +54,21 @@ enum { MUNIT_DTYPE_F32 = 0, MUNIT_DTYPE_BF16 = 1 };
 int munit_version(void);
 const char* munit_last_error(void);
 
+/* Data-parallel exchange for hosts without a communicator of their own (no reference counterpart:
+ * scripts/train.py:171-225 is single-process).  A thin layer over RCCL, resolved with dlopen at the first call (no link-time
+ * dependency; inside a PyTorch process the already-loaded librccl is used).  Rank 0 calls munit_comm_unique_id and hands the
+ * 128 bytes to every rank by its own means; every rank then calls munit_comm_init (collective), on the device it will use.
+ * munit_comm_allreduce sums `count` floats in place over all ranks, asynchronously on `stream` (the flat gradient buffer of
+ * an update; the caller scales by 1/world).  The Python host of this repository uses torch.distributed instead (the launch
+ * contract of bench.py); these entry points are exercised by tests/test_gpu_dp.py at world size 1.
+ * munit_shutdown releases what the library keeps between calls (the RCCL handle). */
+typedef void* munit_comm_t;
+int munit_comm_unique_id(void* id_out, size_t bytes);
+int munit_comm_init(munit_comm_t* comm, int rank, int world, const void* unique_id);
+int munit_comm_allreduce(munit_comm_t comm, float* buf, size_t count, munit_stream_t stream);
+int munit_comm_destroy(munit_comm_t comm);
+int munit_shutdown(void);
+
 /* Stream plumbing (no reference counterpart: torch's autograd engine orders everything on one stream).  `waiter` waits
  * for all work enqueued so far on `signaler`; both streams belong to the current device.  Used to fork backward-weight
  * onto a side stream without creating torch Event / Stream objects per layer. */

@@ -47,6 +47,11 @@ SIGNATURES = {
     "munit_version": (c_int, []),
     "munit_last_error": (c_char_p, []),
     "munit_stream_wait_stream": (c_int, [_P, _P]),
+    "munit_comm_unique_id": (c_int, [_P, c_size_t]),
+    "munit_comm_init": (c_int, [_P, c_int, c_int, _P]),
+    "munit_comm_allreduce": (c_int, [_P, _P, c_size_t, _P]),
+    "munit_comm_destroy": (c_int, [_P]),
+    "munit_shutdown": (c_int, []),
     "munit_conv2d_out_hw": (c_int, [_DESC, POINTER(c_int), POINTER(c_int)]),
     "munit_conv2d_fwd_workspace_bytes": (c_size_t, [_DESC]),
     "munit_conv2d_fwd": (c_int, [_DESC, _P, _P, _P, _P, _P, c_size_t, _P]),

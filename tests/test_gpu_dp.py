@@ -163,3 +163,40 @@ def test_bench_under_torchrun_one_rank():
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp1"
+
+
+_COMM_WORKER = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %(root)r)
+from munit_amd import _lib
+lib = _lib.load()
+torch.cuda.set_device(0)
+uid = (ctypes.c_char * 128)()
+assert lib.munit_comm_unique_id(uid, 128) == 0, lib.munit_last_error()
+comm = ctypes.c_void_p()
+assert lib.munit_comm_init(ctypes.byref(comm), 0, 1, uid) == 0, lib.munit_last_error()
+g = torch.randn(1 << 20, device="cuda:0")
+ref = g.clone()
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    assert lib.munit_comm_allreduce(comm, ctypes.c_void_p(g.data_ptr()), g.numel(), ctypes.c_void_p(st)) == 0, lib.munit_last_error()
+torch.cuda.synchronize()
+assert torch.equal(g, ref)                        # SUM over one rank
+assert lib.munit_comm_allreduce(comm, None, 0, ctypes.c_void_p(st)) == 0
+assert lib.munit_comm_init(ctypes.byref(comm), 2, 1, uid) != 0 and b"bad arguments" in lib.munit_last_error()
+assert lib.munit_comm_destroy(comm) == 0
+assert lib.munit_shutdown() == 0
+print("comm ok")
+"""
+
+
+def test_c_abi_communicator_world1(tmp_path):
+    """munit_comm_unique_id / init / allreduce / destroy + munit_shutdown (SURVEY.md section 8b's RCCL entry points for hosts
+    without torch.distributed), at world size 1 on the box's one GPU, in a child process of its own."""
+    import subprocess
+    script = tmp_path / "comm_w.py"
+    script.write_text(_COMM_WORKER % dict(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT, env=env, timeout=600)
+    assert p.returncode == 0 and "comm ok" in p.stdout.decode(), p.stdout.decode()[-3000:]
+

@@ -31,7 +31,8 @@ def usable_cpus():
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     import torch
-    torch.set_num_threads(usable_cpus())      # the oracle (CPU, fp64) is where the suite's time goes
+    # the oracle (CPU, fp64) is where the suite's time goes; beyond ~32 threads its small fp64 convolutions gain nothing
+    torch.set_num_threads(max(1, min(usable_cpus(), torch.get_num_threads(), 32)))
 
 
 # Collection order of the GPU suite: the fp32 hot path first (op parity, step parity, BASELINE-shape parity), then the

@@ -791,6 +791,41 @@ def mse_const(x, target):
     return _MseConst.apply(x, float(target))
 
 
+class _Act(Function):
+    """LeakyReLU(0.2) / tanh as a layer of its own: the activation of a Conv2dBlock that has a normalisation in front of it
+    (scripts/networks.py:695-701 applies norm, then activation, whatever the pair).  The norm kernels fuse ReLU only -- the
+    configs of the reference never ask for another pair (generator: relu, discriminator: lrelu without a norm), so this path
+    is correctness, not speed: the forward is torch's element-wise kernel, the backward munit_act_bwd on the saved output."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _require(x, "activation input")
+        if x.dtype != torch.float32:
+            raise NotImplementedError("munit_amd: activation after a normalisation layer: fp32 tensors only (got %s)" % x.dtype)
+        x = nhwc(x)
+        if act == "lrelu":
+            y = torch.nn.functional.leaky_relu(x, slope)
+        elif act == "tanh":
+            y = torch.tanh(x)
+        else:
+            raise NotImplementedError("munit_amd: activation %r after a normalisation layer" % act)
+        y = nhwc(y)
+        if MASK_SINK is not None and act == "lrelu":
+            MASK_SINK.append(y > 0)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return act_bwd_raw(ctx.act, ctx.slope, y, nhwc(dy)), None, None
+
+
+def activation(x, act, slope=0.2):
+    return _Act.apply(x, act, float(slope))
+
+
 class _ScalarSum(Function):
     """sum of device scalars with unit weights; backward hands the upstream gradient to every
     term unchanged (no kernel)."""

@@ -200,14 +200,14 @@ def content_encoder(sd: State, pre: str, x: Tensor, hp_gen: dict) -> Tensor:
     return res_blocks(sd, pre + "model.%d." % (nd + 1), h, nr, pt, act, lambda i, j: instance_norm)
 
 
-def mlp(sd: State, pre: str, style: Tensor, n_blk: int = 3) -> Tensor:
-    """MLP / LinearBlock, networks.py:583-597, 704-749: ReLU on all but the last layer
-    (activ='relu' from the gen config is what networks.py:202-209 passes)."""
+def mlp(sd: State, pre: str, style: Tensor, n_blk: int = 3, act: str = "relu") -> Tensor:
+    """MLP / LinearBlock, networks.py:583-597, 704-749: the generator's activation (networks.py:202-209 passes
+    activ=activ; 'relu' in every shipped config) on all but the last layer."""
     h = style.reshape(style.shape[0], -1)
     for i in range(n_blk):
         h = F.linear(h, sd[pre + "model.%d.fc.weight" % i], sd[pre + "model.%d.fc.bias" % i])
         if i < n_blk - 1:
-            h = activation(h, "relu")
+            h = activation(h, act)
     return h
 
 
@@ -260,21 +260,22 @@ class GenView:
     def decode(self, content: Tensor, style: Tensor, k: Optional[int] = None) -> Tensor:
         m = ("mlp%d." % k) if self.double else "mlp."
         d = ("dec%d." % k) if self.double else "dec."
-        params = mlp(self.sd, self.pre + m, style)
+        params = mlp(self.sd, self.pre + m, style, act=self.hp["activ"])
         return decoder(self.sd, self.pre + d, content, params, self.hp)
 
 
 def dis_forward(sd: State, pre: str, x: Tensor, hp_dis: dict) -> List[Tensor]:
     """MsImageDis.forward, networks.py:72-77 with _make_net, networks.py:39-70
-    (norm 'none' only: the configs on the hot path never use another)."""
-    assert hp_dis["norm"] == "none"
+    (norm 'none' -- the configs on the hot path -- or 'in'; the first layer never has a norm, networks.py:41-53)."""
+    assert hp_dis["norm"] in ("none", "in")
+    norm_fn = instance_norm if hp_dis["norm"] == "in" else None
     outs = []
     for s in range(hp_dis["num_scales"]):
         h = x
         p = pre + "cnns.%d." % s
         for l in range(hp_dis["n_layer"]):
             h = conv_block(h, sd[p + "%d.conv.weight" % l], sd[p + "%d.conv.bias" % l], 2, 1,
-                           hp_dis["pad_type"], None, hp_dis["activ"])
+                           hp_dis["pad_type"], norm_fn if l > 0 else None, hp_dis["activ"])
         l = hp_dis["n_layer"]
         outs.append(F.conv2d(h, sd[p + "%d.weight" % l], sd[p + "%d.bias" % l]))
         x = avgpool_3s2(x)

@@ -46,6 +46,24 @@ def test_step_matches_oracle(gs, iters):
     print(rep)
 
 
+@pytest.mark.parametrize("name,size,over", [
+    # three down-samplings on a 72x72 crop: a 9x9 trunk (odd extents: no Winograd tiles, the implicit-GEMM forms), zero padding
+    # everywhere, narrow networks (32 channels at the first layer, 8-dim style, 64-wide MLP), two discriminator scales of
+    # three layers with instance norm
+    ("deep_zero_pad", 72, dict(gen=dict(dim=32, mlp_dim=64, style_dim=8, n_downsample=3, n_res=2, pad_type="zero"),
+                               dis=dict(dim=32, n_layer=3, num_scales=2, pad_type="zero", norm="in"))),
+    # one down-sampling on a 40x40 crop (20x20 trunk), six residual blocks, LeakyReLU generator, one discriminator scale
+    ("shallow_lrelu", 40, dict(gen=dict(dim=64, n_downsample=1, n_res=6, activ="lrelu"),
+                               dis=dict(dim=16, n_layer=2, num_scales=1))),
+])
+def test_step_matches_oracle_on_other_geometries(name, size, over):
+    """The reference builds its networks from the config (scripts/networks.py:121-186, 20-62): the step must match the oracle
+    for geometries other than config_256.yaml's as well -- other depths, widths, paddings and activations reach other kernels
+    (odd extents fall off the Winograd tiles, zero padding takes the other border path, 16 / 32-channel layers the narrow tiles)."""
+    rep = run_step_parity(size=size, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=over)
+    print(name, {k: v for k, v in rep.items() if not isinstance(v, list)})
+
+
 def test_step_unpinned_kinks_stay_within_the_diagnostic_bound():
     """The same comparison without pinning the kinks (each side takes its own ReLU branches): the loose tensors are
     enumerated in the report and may not exceed 10 % of all tensors."""

@@ -667,19 +667,22 @@ class OracleTrainer:
         return grads
 
 
-def synthetic_batch(batch: int, size: int, seed: int = 7, dtype=torch.float32):
-    """SURVEY.md section 8d synthetic inputs: x = 2U-1, mask = (U > 0.5)."""
+def synthetic_batch(batch: int, size, seed: int = 7, dtype=torch.float32):
+    """SURVEY.md section 8d synthetic inputs: x = 2U-1, mask = (U > 0.5).  `size`: an int (square crops) or (height, width)."""
+    h, w = (size, size) if isinstance(size, int) else size
     g = torch.Generator().manual_seed(seed)
-    x_a = (2 * torch.rand(batch, 3, size, size, generator=g) - 1).to(dtype)
-    x_b = (2 * torch.rand(batch, 3, size, size, generator=g) - 1).to(dtype)
-    m_a = (torch.rand(batch, 1, size, size, generator=g) > 0.5).to(dtype)
-    m_b = (torch.rand(batch, 1, size, size, generator=g) > 0.5).to(dtype)
+    x_a = (2 * torch.rand(batch, 3, h, w, generator=g) - 1).to(dtype)
+    x_b = (2 * torch.rand(batch, 3, h, w, generator=g) - 1).to(dtype)
+    m_a = (torch.rand(batch, 1, h, w, generator=g) > 0.5).to(dtype)
+    m_b = (torch.rand(batch, 1, h, w, generator=g) > 0.5).to(dtype)
     return x_a, x_b, m_a, m_b
 
 
-def default_hp(size: int = 256, batch: int = 1, gen_state: int = 1) -> dict:
+def default_hp(size=256, batch: int = 1, gen_state: int = 1) -> dict:
     """configs/config_256.yaml with the benchmark overrides of SURVEY.md section 8d
-    (semantic_w 0, adaptation adv/dfeat 0)."""
+    (semantic_w 0, adaptation adv/dfeat 0).  `size`: an int or (crop_image_height, crop_image_width)."""
+    size_h, size_w = (size, size) if isinstance(size, int) else size
+    size = min(size_h, size_w)
     return dict(
         batch_size=batch, weight_decay=1e-4, beta1=0.5, beta2=0.999, init="kaiming", lr=1e-4,
         lr_policy="step", step_size=100000, gamma=0.5, gan_w=3, recon_x_w=12, recon_s_w=1,
@@ -691,4 +694,4 @@ def default_hp(size: int = 256, batch: int = 1, gen_state: int = 1) -> dict:
         gen=dict(dim=64, mlp_dim=256, style_dim=16, activ="relu", n_downsample=2, n_res=4, pad_type="reflect"),
         dis=dict(dim=64, norm="none", activ="lrelu", n_layer=4, gan_type="lsgan", num_scales=3, pad_type="reflect"),
         ratio_disc_gen=5, input_dim_a=3, input_dim_b=3, display_size=8, optimizer="adam",
-        crop_image_height=size, crop_image_width=size, new_size=size, num_workers=0)
+        crop_image_height=size_h, crop_image_width=size_w, new_size=size, num_workers=0)

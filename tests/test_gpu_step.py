@@ -55,6 +55,11 @@ def test_step_matches_oracle(gs, iters):
     # one down-sampling on a 40x40 crop (20x20 trunk), six residual blocks, LeakyReLU generator, one discriminator scale
     ("shallow_lrelu", 40, dict(gen=dict(dim=64, n_downsample=1, n_res=6, activ="lrelu"),
                                dis=dict(dim=16, n_layer=2, num_scales=1))),
+    # config_256.yaml's networks on crops that are not square (crop_image_height != crop_image_width, utils.py:229-249):
+    # 64 x 96 -> a 16 x 24 trunk, 2 x 3 maps in the last discriminator layer; a kernel that mixes up H and W cannot pass
+    ("non_square", (64, 96), dict()),
+    # gen_state 0 (two AdaINGen, trainer.py:84-97), taller than wide
+    ("non_square_two_generators", (80, 64), dict(gen_state=0)),
 ])
 def test_step_matches_oracle_on_other_geometries(name, size, over):
     """The reference builds its networks from the config (scripts/networks.py:121-186, 20-62): the step must match the oracle

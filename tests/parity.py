@@ -276,7 +276,8 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         rep["grad_l2_median"] = max(rep.get("grad_l2_median", 0.0), gc.median)
         rep.setdefault("grad_kinks", []).extend(gc.kinks)
         for k, v in orc.losses.items():
-            mine = float(getattr(tr, k).detach())
+            mine = getattr(tr, k)          # a disabled term is the int 0, as in the reference (trainer.py:391-400)
+            mine = float(mine.detach()) if torch.is_tensor(mine) else float(mine)
             rel = abs(mine - float(v)) / max(1.0, abs(float(v)))
             rep["loss_rel"] = max(rep["loss_rel"], rel)
             rep[k] = mine

@@ -60,6 +60,9 @@ def test_step_matches_oracle(gs, iters):
     ("non_square", (64, 96), dict()),
     # gen_state 0 (two AdaINGen, trainer.py:84-97), taller than wide
     ("non_square_two_generators", (80, 64), dict(gen_state=0)),
+    # loss terms switched off by the config (trainer.py:501-537 skips what has weight 0): no cycle reconstruction, no style /
+    # content reconstruction -- other tensors reach the backward pass, other branches of gen_update run
+    ("no_cycle_no_latent_recon", 64, dict(recon_x_cyc_w=0, recon_s_w=0, recon_c_w=0)),
 ])
 def test_step_matches_oracle_on_other_geometries(name, size, over):
     """The reference builds its networks from the config (scripts/networks.py:121-186, 20-62): the step must match the oracle
@@ -67,6 +70,14 @@ def test_step_matches_oracle_on_other_geometries(name, size, over):
     (odd extents fall off the Winograd tiles, zero padding takes the other border path, 16 / 32-channel layers the narrow tiles)."""
     rep = run_step_parity(size=size, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=over)
     print(name, {k: v for k, v in rep.items() if not isinstance(v, list)})
+
+
+@pytest.mark.parametrize("batch", [1, 3, 5])
+def test_step_matches_oracle_on_odd_batches(batch):
+    """Batch sizes that do not fill the 8-tile chunks of the Winograd backward-weight or the 64-tile blocks evenly (the
+    guarded load paths, ragged tile lists, split-K tails): config_256.yaml's networks at 64x64."""
+    rep = run_step_parity(size=64, batch=batch, gen_state=1, iters=1, device="cuda:0")
+    print(batch, {k: v for k, v in rep.items() if not isinstance(v, list)})
 
 
 def test_step_unpinned_kinks_stay_within_the_diagnostic_bound():

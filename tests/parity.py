@@ -87,14 +87,16 @@ KINK_FRAC = 1e-3
 
 def oracle_states(hp, dtype):
     gs = hp["gen_state"]
+    nin = hp.get("input_dim_a", 3)
+    assert hp.get("input_dim_b", 3) == nin, "the shared networks of gen_state 1 need input_dim_a == input_dim_b"
     if gs == 1:
-        gen = O.make_state(O.gen_param_shapes(hp["gen"], 3, True), "gen.", dtype)
+        gen = O.make_state(O.gen_param_shapes(hp["gen"], nin, True), "gen.", dtype)
     else:
-        sh = O.gen_param_shapes(hp["gen"], 3, False)
+        sh = O.gen_param_shapes(hp["gen"], nin, False)
         gen = {}
         for tag in ("a", "b"):
             gen.update({tag + "." + k: v for k, v in O.make_state(sh, "gen_%s." % tag, dtype).items()})
-    dsh = O.dis_param_shapes(hp["dis"], 3)
+    dsh = O.dis_param_shapes(hp["dis"], nin)
     return gen, O.make_state(dsh, "dis_a.", dtype), O.make_state(dsh, "dis_b.", dtype)
 
 
@@ -160,6 +162,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
     load_into_trainer(tr, gen, dis_a, dis_b)
     tr.to(device)
     x_a, x_b, m_a, m_b = O.synthetic_batch(batch, size, seed=7)
+    x_a, x_b = x_a[:, :hp["input_dim_a"]].contiguous(), x_b[:, :hp["input_dim_b"]].contiguous()   # input_dim_a / _b < 3: fewer planes
     dx_a, dx_b, dm_a, dm_b = (t.to(device) for t in (x_a, x_b, m_a, m_b))
     ox = [t.to(oracle_dtype) for t in (x_a, x_b, m_a, m_b)]
     rep = {"loss_rel": 0.0, "grad_nerr": 0.0, "weight_nerr": 0.0}

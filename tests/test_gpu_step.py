@@ -72,6 +72,20 @@ def test_step_matches_oracle_on_other_geometries(name, size, over):
     print(name, {k: v for k, v in rep.items() if not isinstance(v, list)})
 
 
+def test_step_matches_oracle_on_one_channel_domains():
+    """input_dim_a = input_dim_b = 1 (networks.py:121-186 builds the first and last layers from them): the three-channel kernels
+    of the image layers do not apply, the generic ones must.  Same bounds as every step test, except for the image head's
+    bias gradient: with one output channel it is ONE number -- a sum over every pixel that largely cancels -- so the max-norm
+    of the tensor cannot absorb its rounding (measured 6e-5 relative; a three-channel head: 4e-6)."""
+    rep = run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=dict(input_dim_a=1, input_dim_b=1),
+                          check=False)
+    print({k: v for k, v in rep.items() if not isinstance(v, list)})
+    assert rep["loss_rel"] <= 1e-5 and rep["grad_l2_median"] <= 1e-5 and rep["weight_l2"] <= 2e-4
+    loose = rep["grad_kinks"]
+    assert all(n.endswith("model.5.conv.bias") and e <= 5e-4 for n, e, _ in loose), loose
+    assert len(loose) <= 2
+
+
 @pytest.mark.parametrize("batch", [1, 3, 5])
 def test_step_matches_oracle_on_odd_batches(batch):
     """Batch sizes that do not fill the 8-tile chunks of the Winograd backward-weight or the 64-tile blocks evenly (the

@@ -63,6 +63,11 @@ def test_step_matches_oracle(gs, iters):
     # loss terms switched off by the config (trainer.py:501-537 skips what has weight 0): no cycle reconstruction, no style /
     # content reconstruction -- other tensors reach the backward pass, other branches of gen_update run
     ("no_cycle_no_latent_recon", 64, dict(recon_x_cyc_w=0, recon_s_w=0, recon_c_w=0)),
+    # config_256.yaml's widths with ZERO padding in both networks: the Winograd kernels' zero-pad border paths (forward,
+    # backward-data without the reflect fold, guarded backward-weight loads) and the zero-padded sub-pixel / stride-2 forms
+    ("zero_pad_full_width", 64, dict(gen=dict(pad_type="zero"), dis=dict(pad_type="zero"))),
+    # a ReLU discriminator of four scales and three layers (MsImageDis takes all three from the config, networks.py:22-30)
+    ("relu_discriminator_4_scales", 64, dict(dis=dict(activ="relu", num_scales=4, n_layer=3))),
 ])
 def test_step_matches_oracle_on_other_geometries(name, size, over):
     """The reference builds its networks from the config (scripts/networks.py:121-186, 20-62): the step must match the oracle

@@ -799,9 +799,7 @@ class _Act(Function):
 
     @staticmethod
     def forward(ctx, x, act, slope):
-        _require(x, "activation input")
-        if x.dtype != torch.float32:
-            raise NotImplementedError("munit_amd: activation after a normalisation layer: fp32 tensors only (got %s)" % x.dtype)
+        _require(x, "activation input", bf16_ok=True)
         x = nhwc(x)
         if act == "lrelu":
             y = torch.nn.functional.leaky_relu(x, slope)
@@ -819,6 +817,9 @@ class _Act(Function):
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
+        if y.dtype != torch.float32:      # bf16 storage: munit_act_bwd is an fp32 kernel; same formula on torch's kernels
+            d = torch.where(y > 0, 1.0, ctx.slope) if ctx.act == "lrelu" else 1.0 - y.float() * y.float()
+            return nhwc((dy.float() * d).to(y.dtype)), None, None
         return act_bwd_raw(ctx.act, ctx.slope, y, nhwc(dy)), None, None
 
 

@@ -415,6 +415,9 @@ class MUNIT_Trainer(nn.Module):
         else:
             raise ValueError("self.gen_state unknown value: %r" % (self.gen_state,))
         if self.precision == "bf16s":
+            if hyperparameters["gen"]["dim"] % 64 != 0:
+                raise ValueError("munit_amd: precision 'bf16s' keeps the generator's activations as bf16 tensors, whose kernels "
+                                 "work on 64-channel rows: gen.dim must be a multiple of 64 (got %d)" % hyperparameters["gen"]["dim"])
             for m in self.modules():
                 if isinstance(m, ContentEncoder):
                     m.store_dtype = torch.bfloat16

@@ -783,6 +783,10 @@ class MUNIT_Trainer(nn.Module):
         self.train()
         return x_a, x_a_recon, x_ab1, x_ab2, x_b, x_b_recon, x_ba1, x_ba2
 
+    def sample_syn(self, x_a, x_b):
+        """trainer.py:930-1085: line for line the body of `sample` under a second name (for synthetic-domain pairs)."""
+        return self.sample(x_a, x_b)
+
     # ---- checkpoints (trainer.py:1337-1429) ---------------------------------------------
     @staticmethod
     def _plain(sd):

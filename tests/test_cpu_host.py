@@ -477,3 +477,31 @@ def test_winograd_algebra_of_the_kernels():
             if 0 <= i < H and not (par == 0 and u == 0) and not (par == 1 and u == Hd):
                 dx[i] = plane[u]
     assert np.abs(dx - dx_ref).max() < 1e-13
+
+
+def test_trainer_method_surface_is_the_reference_s():
+    """The methods of MUNIT_Trainer a training / test script of the reference calls (scripts/trainer.py: __init__ 29, the
+    optimizer steps 252-268, recon_criterion(_mask) 279-305, forward 307, gen_update 336-346, sample 773, sample_syn 930,
+    sample_fid 1087, dis_update 1133, update_learning_rate 1326, resume 1337, save 1387), by name and by parameter list."""
+    import inspect
+    from munit_amd.trainer import MUNIT_Trainer
+    want = {
+        "__init__": ["self", "hyperparameters"],
+        "dis_opt_step": ["self"], "gen_opt_step": ["self"],
+        "recon_criterion": ["self", "input", "target"],
+        "recon_criterion_mask": ["self", "input", "target", "mask"],
+        "forward": ["self", "x_a", "x_b"],
+        "gen_update": ["self", "x_a", "x_b", "hyperparameters", "mask_a", "mask_b", "comet_exp", "synth", "semantic_gt_a",
+                       "semantic_gt_b"],
+        "dis_update": ["self", "x_a", "x_b", "hyperparameters", "comet_exp"],
+        "sample": ["self", "x_a", "x_b"], "sample_syn": ["self", "x_a", "x_b"], "sample_fid": ["self", "x_a", "x_b"],
+        "update_learning_rate": ["self"],
+        "resume": ["self", "checkpoint_dir", "hyperparameters"],
+        "save": ["self", "snapshot_dir", "iterations"],
+    }
+    for name, params in want.items():
+        fn = getattr(MUNIT_Trainer, name)
+        assert list(inspect.signature(fn).parameters) == params, (name, list(inspect.signature(fn).parameters))
+    sig = inspect.signature(MUNIT_Trainer.gen_update).parameters
+    assert sig["comet_exp"].default is None and sig["synth"].default is False and sig["semantic_gt_a"].default is None
+

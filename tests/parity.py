@@ -53,19 +53,28 @@ class GradCheck:
         unpinned:  (diagnostic mode, pin_kinks=False) every tensor <= 5e-2 L2 / 1e-1 max, median <= 2e-3, and at
                    most 10 % of the tensors looser than 1e-2 max -- listed by name in the report."""
 
-    def __init__(self, pinned=True):
+    def __init__(self, pinned=True, overrides=None):
         self.pinned = pinned
+        # {name suffix: bound}: a stated per-tensor exception (both the max-norm and the L2 bound of THAT tensor; every
+        # other tensor, the median, the kink audit and the loss / moment asserts keep the defaults)
+        self.overrides = dict(overrides or {})
         if pinned:
             self.L2_MEDIAN, self.L2_SOFT, self.MAX_SOFT, self.L2_HARD, self.MAX_HARD, self.FRAC = 1e-5, 5e-5, 5e-5, 5e-5, 5e-5, 0.0
         else:
             self.L2_MEDIAN, self.L2_SOFT, self.MAX_SOFT, self.L2_HARD, self.MAX_HARD, self.FRAC = 2e-3, 5e-3, 1e-2, 5e-2, 1e-1, 0.10
-        self.l2s, self.loose, self.worst_max, self.worst_l2 = [], [], 0.0, 0.0
+        self.l2s, self.loose, self.worst_max, self.worst_l2, self.excepted = [], [], 0.0, 0.0, []
         self.kinks = self.loose
 
     def add(self, name, mine, ref, check=True):
         e, l2 = nerr(mine, ref), l2err(mine, ref)
         self.worst_max, self.worst_l2 = max(self.worst_max, e), max(self.worst_l2, l2)
         self.l2s.append(l2)
+        for suffix, bound in self.overrides.items():
+            if name.endswith(suffix):
+                self.excepted.append((name, round(e, 6), round(l2, 6)))
+                if check:
+                    assert l2 <= bound and e <= bound, ("grad (stated exception)", name, e, l2, bound)
+                return
         if e > self.MAX_SOFT or l2 > self.L2_SOFT:
             self.loose.append((name, round(e, 5), round(l2, 5)))
         if check:
@@ -133,7 +142,7 @@ def trainer_named_params(trainer):
 
 def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", oracle_dtype=torch.float64,
                     step_size=2, check=True, optimizer="adam", precision=None, guided=1, recon_mask=1, pin_kinks=True,
-                    ref32=False, hp_overrides=None):
+                    ref32=False, hp_overrides=None, grad_overrides=None):
     """dis_update + gen_update pairs on the HIP trainer vs the oracle.  Returns a report dict;
     with check=True asserts the tolerances of SURVEY.md section 8c (vs the fp64 oracle:
     losses 1e-5 relative; gradients: GradCheck; weights after Adam: see the comment at the end).
@@ -180,7 +189,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
             with torch.no_grad():
                 for (n, p), q in list(zip(gnames, o_gen)) + list(zip(dnames, o_dis)):
                     q.copy_(p.detach().to(oracle_dtype).cpu())
-        gc = GradCheck(pinned=pin_kinks)
+        gc = GradCheck(pinned=pin_kinks, overrides=grad_overrides)
         tr.iterations = orc.iterations = it  # train.py:157,328: the caller owns the counter
         tr.update_learning_rate()
         orc.update_learning_rate()
@@ -278,6 +287,7 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         rep["grad_l2"] = max(rep.get("grad_l2", 0.0), gc.worst_l2)
         rep["grad_l2_median"] = max(rep.get("grad_l2_median", 0.0), gc.median)
         rep.setdefault("grad_kinks", []).extend(gc.kinks)
+        rep.setdefault("grad_excepted", []).extend(gc.excepted)
         for k, v in orc.losses.items():
             mine = getattr(tr, k)          # a disabled term is the int 0, as in the reference (trainer.py:391-400)
             mine = float(mine.detach()) if torch.is_tensor(mine) else float(mine)
@@ -296,7 +306,12 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
             for (n, p), (mv, vv), om, ov, q in zip(names_, opt_mine._views, o["m"], o["v"], o["params"]):
                 if n in null:
                     continue
-                rep["moment_l2"] = max(rep.get("moment_l2", 0.0), l2err(mv, om), l2err(vv, ov))
+                exc = [b for sfx, b in (grad_overrides or {}).items() if n.endswith(sfx)]
+                if exc:      # a tensor with a stated gradient exception: its moments are linear / quadratic in that gradient
+                    if check:
+                        assert max(l2err(mv, om), l2err(vv, ov)) <= 4 * exc[0], ("moment (stated exception)", n)
+                else:
+                    rep["moment_l2"] = max(rep.get("moment_l2", 0.0), l2err(mv, om), l2err(vv, ov))
                 a, r = p.detach().double().cpu(), q.detach().double()
                 if o_key == "dis":  # the oracle's D was overwritten after its step: use the saved pair
                     _, a, r = d_step[[x[0] for x in d_step].index(n)]

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import munit_oracle as O
+from tests.geometries import GEOMETRIES, ONE_CHANNEL
 from tests.parity import load_into_trainer, nerr, oracle_states, run_step_parity
 
 pytestmark = pytest.mark.gpu
@@ -46,49 +47,28 @@ def test_step_matches_oracle(gs, iters):
     print(rep)
 
 
-@pytest.mark.parametrize("name,size,over", [
-    # three down-samplings on a 72x72 crop: a 9x9 trunk (odd extents: no Winograd tiles, the implicit-GEMM forms), zero padding
-    # everywhere, narrow networks (32 channels at the first layer, 8-dim style, 64-wide MLP), two discriminator scales of
-    # three layers with instance norm
-    ("deep_zero_pad", 72, dict(gen=dict(dim=32, mlp_dim=64, style_dim=8, n_downsample=3, n_res=2, pad_type="zero"),
-                               dis=dict(dim=32, n_layer=3, num_scales=2, pad_type="zero", norm="in"))),
-    # one down-sampling on a 40x40 crop (20x20 trunk), six residual blocks, LeakyReLU generator, one discriminator scale
-    ("shallow_lrelu", 40, dict(gen=dict(dim=64, n_downsample=1, n_res=6, activ="lrelu"),
-                               dis=dict(dim=16, n_layer=2, num_scales=1))),
-    # config_256.yaml's networks on crops that are not square (crop_image_height != crop_image_width, utils.py:229-249):
-    # 64 x 96 -> a 16 x 24 trunk, 2 x 3 maps in the last discriminator layer; a kernel that mixes up H and W cannot pass
-    ("non_square", (64, 96), dict()),
-    # gen_state 0 (two AdaINGen, trainer.py:84-97), taller than wide
-    ("non_square_two_generators", (80, 64), dict(gen_state=0)),
-    # loss terms switched off by the config (trainer.py:501-537 skips what has weight 0): no cycle reconstruction, no style /
-    # content reconstruction -- other tensors reach the backward pass, other branches of gen_update run
-    ("no_cycle_no_latent_recon", 64, dict(recon_x_cyc_w=0, recon_s_w=0, recon_c_w=0)),
-    # config_256.yaml's widths with ZERO padding in both networks: the Winograd kernels' zero-pad border paths (forward,
-    # backward-data without the reflect fold, guarded backward-weight loads) and the zero-padded sub-pixel / stride-2 forms
-    ("zero_pad_full_width", 64, dict(gen=dict(pad_type="zero"), dis=dict(pad_type="zero"))),
-    # a ReLU discriminator of four scales and three layers (MsImageDis takes all three from the config, networks.py:22-30)
-    ("relu_discriminator_4_scales", 64, dict(dis=dict(activ="relu", num_scales=4, n_layer=3))),
-])
+@pytest.mark.parametrize("name,size,over", GEOMETRIES, ids=[g[0] for g in GEOMETRIES])
 def test_step_matches_oracle_on_other_geometries(name, size, over):
     """The reference builds its networks from the config (scripts/networks.py:121-186, 20-62): the step must match the oracle
+    (pinned to the reference modules on each of these geometries: tests/golden/golden_geometries.json,
+    tests/test_oracle_golden.py::test_step_geometries_match_reference_sequence)
     for geometries other than config_256.yaml's as well -- other depths, widths, paddings and activations reach other kernels
     (odd extents fall off the Winograd tiles, zero padding takes the other border path, 16 / 32-channel layers the narrow tiles)."""
-    rep = run_step_parity(size=size, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=over)
+    rep = run_step_parity(size=size, batch=2, gen_state=over.get("gen_state", 1), iters=1, device="cuda:0", hp_overrides=over)
     print(name, {k: v for k, v in rep.items() if not isinstance(v, list)})
 
 
 def test_step_matches_oracle_on_one_channel_domains():
     """input_dim_a = input_dim_b = 1 (networks.py:121-186 builds the first and last layers from them): the three-channel kernels
-    of the image layers do not apply, the generic ones must.  Same bounds as every step test, except for the image head's
-    bias gradient: with one output channel it is ONE number -- a sum over every pixel that largely cancels -- so the max-norm
-    of the tensor cannot absorb its rounding (measured 6e-5 relative; a three-channel head: 4e-6)."""
-    rep = run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=dict(input_dim_a=1, input_dim_b=1),
-                          check=False)
-    print({k: v for k, v in rep.items() if not isinstance(v, list)})
-    assert rep["loss_rel"] <= 1e-5 and rep["grad_l2_median"] <= 1e-5 and rep["weight_l2"] <= 2e-4
-    loose = rep["grad_kinks"]
-    assert all(n.endswith("model.5.conv.bias") and e <= 5e-4 for n, e, _ in loose), loose
-    assert len(loose) <= 2
+    of the image layers do not apply, the generic ones must.  Every check of the step tests is ON (kink audit, losses, moments,
+    weights, every gradient tensor at 5e-5) with ONE stated per-tensor exception: the image head's bias gradient.  With one
+    output channel it is ONE number -- a sum over every pixel that largely cancels -- so the max-norm of the tensor cannot
+    absorb its rounding (measured 6e-5 relative; a three-channel head: 4e-6): held to 5e-4."""
+    name, size, over = ONE_CHANNEL
+    rep = run_step_parity(size=size, batch=2, gen_state=1, iters=1, device="cuda:0", hp_overrides=over,
+                          grad_overrides={"model.5.conv.bias": 5e-4})
+    print({k: v for k, v in rep.items() if not isinstance(v, list)}, rep["grad_excepted"])
+    assert 1 <= len(rep["grad_excepted"]) <= 2 and not rep["grad_kinks"]
 
 
 @pytest.mark.parametrize("batch", [1, 3, 5])

@@ -177,3 +177,71 @@ def test_extraadam_matches_reference_file():
         assert np.abs(got - g["trace"][k]).max() <= 1e-14, (k, mode)
     with pytest.raises(RuntimeError):
         st.step([torch.zeros(7, 5, dtype=torch.float64), torch.zeros(11, dtype=torch.float64)])
+
+
+def _geometry_names():
+    from tests.geometries import ALL
+    return [g[0] for g in ALL]
+
+
+@pytest.mark.parametrize("name", _geometry_names())
+def test_step_geometries_match_reference_sequence(name):
+    """Every geometry of tests/geometries.py -- the list the GPU step-parity tests iterate -- pinned to the reference MODULES
+    built from that geometry's config (tests/golden/make_golden_geometries.py: networks.py:170-209, 262-388, 442-563, 20-115
+    driven per trainer.py:365-561 / 1145-1186): forward digests, every loss_*, every gradient tensor, weights after one
+    dis_update + gen_update, float64.  A geometry without a fixture fails here (KeyError), so the GPU suite cannot compare the
+    HIP path to an oracle the reference has not pinned."""
+    import json
+    import os
+    from tests.geometries import ALL, merged_hp
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_geometries.json")))[name]
+    _, size, over = [g for g in ALL if g[0] == name][0]
+    assert rec["over"] == json.loads(json.dumps(over)) and rec["size"] == (size if isinstance(size, int) else list(size)), \
+        "tests/geometries.py changed: regenerate tests/golden/golden_geometries.json"
+    hp = merged_hp(O.default_hp, size, over, rec["batch"])
+    nin = hp["input_dim_a"]
+    dtype = torch.float64
+    if hp["gen_state"] == 1:
+        gen = O.make_state(O.gen_param_shapes(hp["gen"], nin, True), "gen.", dtype)
+    else:
+        sh = O.gen_param_shapes(hp["gen"], nin, False)
+        gen = {}
+        for tag in ("a", "b"):
+            gen.update({tag + "." + k: v for k, v in O.make_state(sh, "gen_%s." % tag, dtype).items()})
+    dsh = O.dis_param_shapes(hp["dis"], nin)
+    dis_a, dis_b = O.make_state(dsh, "dis_a.", dtype), O.make_state(dsh, "dis_b.", dtype)
+    tr = O.OracleTrainer(hp, gen, dis_a, dis_b)
+    x_a, x_b, m_a, m_b = (t.double() for t in O.synthetic_batch(rec["batch"], size, seed=7))
+    x_a, x_b = x_a[:, :nin].contiguous(), x_b[:, :nin].contiguous()
+    # forward digests on the initial weights
+    (ga, ka), (gb, kb) = tr._views()
+    with torch.no_grad():
+        c_a, s_a = ga.encode(x_a, ka)
+        c_b, s_b = gb.encode(x_b, kb)
+        x_ba, x_ab = ga.decode(c_b, s_a, ka), gb.decode(c_a, s_b, kb)
+        d = O.dis_forward(tr.dis_a, "", x_ba, hp["dis"])
+    f = rec["forward"]
+    close_digest(dg(c_a), f["content"], 1e-10)
+    close_digest(dg(s_b), f["style"], 1e-10)
+    close_digest(dg(x_ba), f["x_ba"], 1e-10)
+    close_digest(dg(x_ab), f["x_ab"], 1e-10)
+    assert len(d) == len(f["dis"])
+    for o, e in zip(d, f["dis"]):
+        close_digest(dg(o), e, 1e-10)
+    tr.update_learning_rate()
+    dgr = tr.dis_update(x_a, x_b)
+    ggr = tr.gen_update(x_a, x_b, m_a, m_b)
+    for k, v in rec["losses"].items():
+        assert abs(float(tr.losses[k]) - v) <= 1e-9 * max(1.0, abs(v)), (k, float(tr.losses[k]), v)
+    assert len(dgr) == len(rec["dis_grad"]) and len(ggr) == len(rec["gen_grad"])
+    for g_, d_ in zip(dgr, rec["dis_grad"]):
+        close_digest(dg(g_), d_, 1e-8, 1e-11)
+    for g_, d_ in zip(ggr, rec["gen_grad"]):
+        if d_ is not None:
+            close_digest(dg(g_), d_, 1e-8, 1e-11)
+        else:
+            assert g_ is None or float(g_.abs().max()) == 0.0
+    for p, d_ in zip(tr.opt["gen"]["params"], rec["gen_after"]):
+        close_digest(dg(p), d_, 1e-9)
+    for p, d_ in zip(tr.opt["dis"]["params"], rec["dis_after"]):
+        close_digest(dg(p), d_, 1e-9)

@@ -122,12 +122,24 @@ def cpu_quota():
         return None
 
 
-def host_cores():
-    """Threads of the CPU baseline: the physical cores of one socket, capped by what the cgroup
-    lets the process use -- more threads than the quota only get throttled."""
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs and grant 16) -- the same rule as tests/conftest.py.  Everything in this file that sizes a thread pool goes through
+    here; os.cpu_count() counts what the box SHOWS."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     q = cpu_quota()
-    n = _socket_cores()
-    return n if q is None else max(1, min(n, q))
+    return max(1, n if q is None else min(n, q))
+
+
+def rank_threads(n_ranks):
+    """Host threads per rank when n_ranks share this machine's CPU grant (OMP_NUM_THREADS of the self-launched ranks)."""
+    return max(1, usable_cpus() // max(1, n_ranks))
+
+
+def host_cores():
+    """Threads of the CPU baseline: the physical cores of one socket, capped by what the process may
+    use (affinity and cgroup quota) -- more threads than that only get throttled."""
+    return max(1, min(_socket_cores(), usable_cpus()))
 
 
 def _socket_cores():
@@ -148,7 +160,7 @@ def _socket_cores():
             return max(1, len(seen) // sockets)
     except OSError:
         pass
-    return max(1, (os.cpu_count() or 2) // 2)
+    return max(1, usable_cpus())
 
 
 def cpu_baseline(size, seconds_budget=45.0):
@@ -192,6 +204,41 @@ def cpu_baseline(size, seconds_budget=45.0):
             "config0_128x128_b1": {"value": round(v128, 4), "unit": "images/s", "timed_steps": n128}}
 
 
+def time_configuration(dev, size, batch, precision, peak_tflops, warmup=3, steps=5):
+    """One of BASELINE.json's other single-GPU configurations, timed the way the metric is (update_learning_rate + dis_update +
+    gen_update on a resident synthetic batch, wall clock between device synchronisations) on a fresh trainer."""
+    from munit_amd.trainer import MUNIT_Trainer
+    hp = bench_hp(size, batch)
+    hp["precision"] = precision
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(hp)
+    tr.to(dev)
+    x_a, x_b, m_a, m_b = (t.to(dev) for t in make_batch(batch, size))
+
+    def step():
+        tr.update_learning_rate()
+        tr.dis_update(x_a, x_b, hp)
+        tr.gen_update(x_a, x_b, hp, m_a, m_b)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(tr.loss_gen_total)
+    assert loss == loss, "loss is NaN"
+    step_flop = GFLOP_PER_PAIR_256 * 1e9 * (size / 256.0) ** 2 * batch
+    return {"workload": "%dx%d, batch %d, %s" % (size, size, batch, precision), "ms_per_step": round(1e3 * dt, 3),
+            "images_per_s": round(batch / dt, 3), "steps": steps, "warmup": warmup, "loss_gen_total": round(loss, 5),
+            "roofline": {"bound": "mfma", "peak": peak_tflops, "unit": "TFLOP/s",
+                         "achieved": round(step_flop / dt / 1e12, 2), "frac": round(step_flop / dt / 1e12 / peak_tflops, 4),
+                         "pricing": "algorithmic conv+linear FLOPs of the step (SURVEY.md 8d) / step time",
+                         "step_algorithmic_tflop": round(step_flop / 1e12, 3)},
+            "note": "supplementary; not the reported metric"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: run the N ranks as children of this (GPU-free) process through
     torch.distributed.run, relay rank 0's JSON line on stdout (everything else goes to stderr) and return non-zero
@@ -204,7 +251,7 @@ def self_launch(n):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(rank_threads(n)))      # the CPUs the cgroup grants, shared by the ranks
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
@@ -281,6 +328,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if use_dist:
+        torch.set_num_threads(rank_threads(world))      # host threads: this rank's share of the CPUs the cgroup grants
 
     from munit_amd import _lib, ops
     _lib.load()  # fail loudly before anything else if the HIP library is missing
@@ -472,6 +521,17 @@ def main():
         out["other_modes"]["reuse_dis_forward"] = {"ms_per_step": round(1e3 * dt, 3), "images_per_s": round(args.batch / dt, 3),
                                                    "note": "opt-in; not the reported metric"}
         del tr3
+        if (args.size, args.batch, args.gen_state) == (256, 8, 1):
+            # The two other single-GPU configurations of BASELINE.json, timed in the same process after the metric's own timed
+            # region (3 warm-up + 5 timed steps each, wall clock between device synchronisations; never `value`): configs[3] =
+            # config_HD.yaml 512x512 batch 4 fp32, configs[2] = 256x256 batch 32 with bf16 storage + bf16 MFMA.  `step_frac` =
+            # SURVEY.md 8d's algorithmic FLOPs of the step / step time / the dense MFMA peak of the mode's arithmetic.
+            torch.cuda.empty_cache()
+            for name, size_m, batch_m, prec_m, peak in (("config_hd_512_b4", 512, 4, "f32", PEAK_F32_MFMA_TFLOPS),
+                                                        ("bf16s_256_b32", 256, 32, "bf16s", PEAK_BF16_MFMA_TFLOPS)):
+                out["other_modes"][name] = time_configuration(dev, size_m, batch_m, prec_m, peak)
+                torch.cuda.empty_cache()
+            ops.set_compute("f32")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     if rank == 0:

@@ -61,7 +61,8 @@ const char* munit_last_error(void);
  * munit_comm_allreduce sums `count` floats in place over all ranks, asynchronously on `stream` (the flat gradient buffer of
  * an update; the caller scales by 1/world).  The Python host of this repository uses torch.distributed instead (the launch
  * contract of bench.py); these entry points are exercised by tests/test_gpu_dp.py at world size 1.
- * munit_shutdown releases what the library keeps between calls (the RCCL handle). */
+ * munit_shutdown releases what the library keeps between calls (the RCCL handle); it is refused with MUNIT_ERR_ARG while a
+ * communicator made by munit_comm_init is still alive.  The first call from several host threads is serialised. */
 typedef void* munit_comm_t;
 int munit_comm_unique_id(void* id_out, size_t bytes);
 int munit_comm_init(munit_comm_t* comm, int rank, int world, const void* unique_id);
@@ -187,7 +188,8 @@ int munit_act_bwd(int act, float slope, const float* y, const float* dy, float* 
  *   y = act( (x - mean) * rsqrt(var + eps) * weight[b][c] + bias[b][c] ) + residual
  * adain == NULL -> weight 1 / bias 0.  Otherwise weight[b][c] = adain[b*ad_ld + w_off + c],
  * bias[b][c] = adain[b*ad_ld + b_off + c] (the slicing of assign_adain_params,
- * networks.py:230-239, done by address).  relu: 0/1.  residual may be NULL
+ * networks.py:230-239, done by address).  relu: the activation act() as MUNIT_ACT_* -- 0 none, 1 ReLU,
+ * 2 LeakyReLU(0.2), 3 tanh (networks.py:668-681 pairs any norm with any activation).  residual may be NULL
  * (ResBlock's `out += residual`, networks.py:620-624).
  * stats: [B][C][2] (mean, rstd) written for the backward.  C % 4 == 0.
  * ------------------------------------------------------------------------------------ */
@@ -211,7 +213,7 @@ int munit_instnorm_bwd_bf16(const void* x, const void* dy, const float* stats, v
 
 /* ------------------------------------------------------------------------------------
  * MUNIT's custom LayerNorm (scripts/networks.py:851-878): per-sample mean and UNBIASED
- * std over C*H*W, y = act( (x - mean) / (std + eps) * gamma[c] + beta[c] ).
+ * std over C*H*W, y = act( (x - mean) / (std + eps) * gamma[c] + beta[c] ), act = MUNIT_ACT_* in `relu`.
  * stats: [B][2] (mean, std).  C % 4 == 0.
  * ------------------------------------------------------------------------------------ */
 size_t munit_layernorm_workspace_bytes(int B, int HW, int C);

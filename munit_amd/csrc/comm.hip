@@ -5,7 +5,9 @@
 // NOT use these entry points: its exchange is torch.distributed's process group (the launch contract), see DESIGN.md section 6.
 #include "common.h"
 #include <dlfcn.h>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 
 namespace {
 struct UniqueId { char internal[128]; };                 // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
@@ -25,8 +27,13 @@ struct Rccl {
   get_error_string_t error_string = nullptr;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mutex;                 // first use from two host threads, and shutdown against a first use
+std::atomic<int> g_live_comms{0};        // communicators created through this library and not yet destroyed
 
+// Resolves librccl once; callers hold no lock afterwards (the table is written before `handle` is published and never changes
+// while a communicator lives: munit_shutdown refuses to unload it then).
 bool load_rccl() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle != nullptr) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
@@ -56,7 +63,8 @@ bool load_rccl() {
 
 int check(int rc, const char* what) {
   if (rc == 0) return MUNIT_OK;
-  munit_set_error("munit_comm: %s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(rc) : "rccl error");
+  if (g_rccl.error_string != nullptr) munit_set_error("munit_comm: %s failed: %s", what, g_rccl.error_string(rc));
+  else munit_set_error("munit_comm: %s failed: ncclResult_t %d (this librccl exports no ncclGetErrorString)", what, rc);
   return MUNIT_ERR_LAUNCH;
 }
 }  // namespace
@@ -77,7 +85,10 @@ extern "C" int munit_comm_init(munit_comm_t* comm, int rank, int world, const vo
   memcpy(&id, unique_id, sizeof(id));
   void* c = nullptr;
   const int rc = check(g_rccl.comm_init_rank(&c, world, id, rank), "ncclCommInitRank");
-  if (rc == MUNIT_OK) *comm = c;
+  if (rc == MUNIT_OK) {
+    *comm = c;
+    g_live_comms.fetch_add(1);
+  }
   return rc;
 }
 
@@ -91,12 +102,20 @@ extern "C" int munit_comm_allreduce(munit_comm_t comm, float* buf, size_t count,
 extern "C" int munit_comm_destroy(munit_comm_t comm) {
   if (comm == nullptr) return MUNIT_OK;
   if (!load_rccl()) return MUNIT_ERR_LAUNCH;
-  return check(g_rccl.comm_destroy(comm), "ncclCommDestroy");
+  const int rc = check(g_rccl.comm_destroy(comm), "ncclCommDestroy");
+  if (rc == MUNIT_OK) g_live_comms.fetch_sub(1);
+  return rc;
 }
 
-// Frees what the library keeps between calls: the RCCL handle (communicators must have been destroyed by their owners).
+// Frees what the library keeps between calls: the RCCL handle.  Refused (MUNIT_ERR_ARG, nothing unloaded) while a
+// communicator created by munit_comm_init is still alive: its owner destroys it first.
 // HIP modules, the cached stream-wait events and the thread-local error string are process-lifetime state of the runtime.
 extern "C" int munit_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (g_live_comms.load() > 0) {
+    munit_set_error("munit_shutdown: %d communicator(s) still alive; call munit_comm_destroy first", g_live_comms.load());
+    return MUNIT_ERR_ARG;
+  }
   if (g_rccl.handle != nullptr) {
     dlclose(g_rccl.handle);
     g_rccl = Rccl{};

@@ -1223,7 +1223,8 @@ extern "C" const char* munit_conv2d_kernel_name(const munit_conv_desc* d, int pa
     const bool fast = ((long long)d->B * (d->H / 2) * (d->W / 2)) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT;
     return fast ? "conv_wino_wgrad_kernel<false, true, false> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<false, false, false> + wino_wgrad_reduce_kernel";
   }
-  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD")) return "conv_lanes_wgrad_kernel";
+  if (munit_small_wgrad_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_WGRAD"))   // mirrors munit_small_wgrad's choice
+    return MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WGRAD_PK") ? "conv_lanes_wgrad_kernel" : "conv_lanes_wgrad_pk_kernel";
   if (subpixel_wgrad_ok(d)) {
     SubpixelPlan sp;
     plan_subpixel(d, &sp);

@@ -155,7 +155,51 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) off[i * 4 + j] = (ro[i] >= 0 && co[j] >= 0) ? (unsigned)(ro[i] + co[j]) * 4u : 0x80000000u;
   };
-  make_off(0);
+  // Phase-major contractions (PHK): the 16 offsets change with the phase (row parity r = phase >> 1 moves the four row terms,
+  // column parity the four column terms).  Re-deriving them inside the loop keeps the tile coordinates, p.H / p.W / p.xc and
+  // the reflection logic live next to 128 accumulators + the prefetched U fragments -- over the 256-register limit (9 - 11
+  // spilled registers in the 4x4 / stride 2 forward kernels).  Instead the prologue writes the thread's eight row terms (r = 0, 1)
+  // and eight column terms (s = 0, 1) to a private LDS column behind the V buffers, and a phase change is 8 ds_read_b32 + 16
+  // saturating adds: nothing but that column's address survives the prologue.
+  unsigned* const otab = reinterpret_cast<unsigned*>(smem + 2 * VBUF) + (tid & 255);   // [16][256]: entry k of this thread at k * 256
+  auto term_table = [&]() {
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ih, iw;
+        if constexpr (S2) {
+          ih = 2 * (3 * gy + i) + par - 1;
+          iw = 2 * (3 * gx + i) + par - 1;
+          if (REFLECT) {
+            ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
+            iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
+          }
+        } else {   // UPD
+          ih = 2 * (2 * gy + 1 + i) + par; iw = 2 * (2 * gx + 1 + i) + par;
+        }
+        // an invalid term carries bit 31: the sum of two terms saturates to 0x80000000 (beyond any buffer) when either is set
+        otab[(par * 4 + i) * 256] = (unsigned)ih < (unsigned)p.H ? (unsigned)((gb * p.H + ih) * p.W * p.xc) * 4u : 0x80000000u;
+        otab[(8 + par * 4 + i) * 256] = (unsigned)iw < (unsigned)p.W ? (unsigned)(iw * p.xc + 2 * cp) * 4u : 0x80000000u;
+      }
+  };
+  auto load_off = [&](int phase) {
+    unsigned ro[4], co[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ro[i] = otab[((phase >> 1) * 4 + i) * 256];
+      co[i] = otab[(8 + (phase & 1) * 4 + i) * 256];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) off[i * 4 + j] = ((ro[i] | co[j]) & 0x80000000u) ? 0x80000000u : ro[i] + co[j];
+  };
+  if constexpr (PHK) {
+    if (loader) { term_table(); load_off(0); }
+  } else {
+    make_off(0);
+  }
   int off_phase = 0;
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   f32x2 d[16];
@@ -164,7 +208,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     if constexpr (PHK) {
       const int phase = c / p.cpp;
       cc = c - phase * p.cpp;
-      if (phase != off_phase) { make_off(phase); off_phase = phase; }   // wave-uniform
+      if (phase != off_phase) { load_off(phase); off_phase = phase; }   // wave-uniform
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) d[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, off[q], cc * (WK * 4), 0));
@@ -334,7 +378,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
     for (int i = 0; i < 4; ++i) g_wino_stamps[(blockIdx.x * 8 + wave) * 4 + i] = st_acc[i];
 #endif
   // ---- epilogue: M[f][tile][32 channels] planes through LDS, two halves ----
-  const int co = tid & 31;
+  // every per-thread index of the epilogue derives from this opaque copy, so none of them can be formed before the main loop and
+  // parked in scratch memory across it (the loop runs at the 256-register limit)
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63;
+  // ... and the tile-list divisions of the epilogue use opaque copies of their divisors: otherwise the compiler shares the
+  // reciprocals it formed for the loader's divisions in the prologue and carries them through the loop in (spilled) registers
+  int tw_e = p.tw, th_e = p.th;
+  asm volatile("" : "+s"(tw_e), "+s"(th_e));
+  const int co = tid_e & 31;
   const float slope = p.slope;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -346,13 +399,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
         for (int ntl = 0; ntl < 2; ++ntl)
 #pragma unroll
           for (int r = 0; r < 4; ++r)   // C/D map: col = lane & 15, row = 4 * (lane >> 4) + r
-            smem[((wave * 2 + fq) * 64 + mt * 16 + 4 * (lane >> 4) + r) * MLD + ntl * 16 + (lane & 15)] = acc[fq][mt][half * 2 + ntl][r];
+            smem[((wave * 2 + fq) * 64 + mt * 16 + 4 * (lane_e >> 4) + r) * MLD + ntl * 16 + (lane_e & 15)] = acc[fq][mt][half * 2 + ntl][r];
     __syncthreads();
     const int n = n_blk * 64 + half * 32 + co;
     const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int t2 = (tid >> 5) + 16 * it;
+      const int t2 = (tid_e >> 5) + 16 * it;
       float m[16];
 #pragma unroll
       for (int f = 0; f < 16; ++f) m[f] = smem[(f * 64 + t2) * MLD + co];
@@ -365,8 +418,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           s[8 + j] = (m[4 + j] + m[8 + j]) - m[12 + j];
         }
         const int t = m_blk0 * 64 + t2;
-        if (t < p.B * p.th * p.tw) {
-          const int tx = t % p.tw, ty = (t / p.tw) % p.th, tb = t / (p.tw * p.th);
+        if (t < p.B * th_e * tw_e) {
+          const int tx = t % tw_e, ty = (t / tw_e) % th_e, tb = t / (tw_e * th_e);
           const int ph = phase >> 1, pw = phase & 1;
           float v[3][3];
 #pragma unroll
@@ -377,25 +430,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           }
           // plane index u = 3 ty + i  <->  padded row 2u + ph  <->  image row 2u + ph - 1.  Fold rows: u = 0 of parity 0 onto
           // u = 1; u = H (the plane's last) of parity 1 onto u = H - 1; columns likewise.  p.H, p.W = extent of dy.
-          const int fr = ph == 0 ? 0 : p.H, fc = pw == 0 ? 0 : p.W;   // folding plane row / column
-          const int dr = ph == 0 ? 1 : -1, dc = pw == 0 ? 1 : -1;     // its target sits one step inside
+          const int fr = ph == 0 ? 0 : p.H, fc = pw == 0 ? 0 : p.W;   // folding plane row / column; its target sits one step inside
           if (REFLECT) {
+            // every index below is a compile-time constant: a run-time `v[i + dr][j]` sends the 3x3 values to scratch memory
+            const int ir = fr - 3 * ty, jc = fc - 3 * tx;   // position of the folding row / column inside this tile (if 0..2)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (3 * ty + i == fr) {
+            for (int j = 0; j < 3; ++j) {
+              if (ph == 0) { if (ir == 0) v[1][j] += v[0][j]; }
+              else { if (ir == 1) v[0][j] += v[1][j]; else if (ir == 2) v[1][j] += v[2][j]; }
+            }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                  if (i + dr >= 0 && i + dr < 3) v[i + dr][j] += v[i][j];
-                }
-              }
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-              if (3 * tx + j == fc) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                  if (j + dc >= 0 && j + dc < 3) v[i][j + dc] += v[i][j];
-                }
-              }
+            for (int i = 0; i < 3; ++i) {
+              if (pw == 0) { if (jc == 0) v[i][1] += v[i][0]; }
+              else { if (jc == 1) v[i][0] += v[i][1]; else if (jc == 2) v[i][1] += v[i][2]; }
+            }
           }
           float* yb = p.y + tb * p.y_sb + n;
 #pragma unroll
@@ -419,8 +467,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(WinoParams p) {
           s[8 + j] = (m[4 + j] + m[8 + j]) - m[12 + j];
         }
         const int t = m_blk0 * 64 + t2;
-        if (t < p.B * p.th * p.tw) {
-          const int tx = t % p.tw, ty = (t / p.tw) % p.th, tb = t / (p.tw * p.th);
+        if (t < p.B * th_e * tw_e) {
+          const int tx = t % tw_e, ty = (t / tw_e) % th_e, tb = t / (tw_e * th_e);
           float* yp = p.y + tb * p.y_sb + (long long)(3 * ty) * p.y_sh + (long long)(3 * tx) * p.y_sw + n;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {

@@ -16,6 +16,24 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAX_SPLIT = 64;
 
+// Activation behind the normalisation (networks.py:668-681, 695-701 pair any norm with any activation).  The `relu` argument of
+// the entry points is an activation code: 0 none, 1 ReLU, 2 LeakyReLU(0.2) (the reference's fixed slope, networks.py:672),
+// 3 tanh = MUNIT_ACT_*.  The backward kernels re-evaluate the forward's own pre-activation expression bit for bit and
+// differentiate the activation there (ReLU / LeakyReLU: the branch the forward took; tanh: 1 - tanh(pre)^2, the same tanhf).
+constexpr float NORM_LRELU_SLOPE = 0.2f;
+__device__ inline float norm_act(float v, int act) {
+  if (act == MUNIT_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == MUNIT_ACT_LRELU) return v > 0.f ? v : v * NORM_LRELU_SLOPE;
+  if (act == MUNIT_ACT_TANH) return tanhf(v);
+  return v;
+}
+__device__ inline float norm_act_grad(float pre, float g, int act) {
+  if (act == MUNIT_ACT_RELU) return pre > 0.f ? g : 0.f;
+  if (act == MUNIT_ACT_LRELU) return pre > 0.f ? g : g * NORM_LRELU_SLOPE;
+  if (act == MUNIT_ACT_TANH) { const float t = tanhf(pre); return g * (1.f - t * t); }
+  return g;
+}
+
 // layout of the thread block over an NHWC plane: QB channel-quads x PL pixel lanes
 struct Lay {
   int CQ;  // C/4
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, T
     v = v * sc + sh;
     if (relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = norm_act(v[e], relu);
     }
     if (residual != nullptr) v += ld4(residual + base + i * 4);
     st4(y + base + i * 4, v);
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(NT) void in_bwd_stats_kernel(const T* __restrict__ 
         f32x4 g = ld4(dy + o);
         if (relu) {   // the branch the FORWARD took: the same x * scale + shift, bit for bit (in_finalize / in_apply)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < 4; ++e) g[e] = norm_act_grad(xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e]), g[e], relu);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_kernel(const T* __restrict__ 
     f32x4 g = ld4(dy + base + i * 4);
     if (relu) {   // the forward's own x * scale + shift (see in_bwd_stats_kernel)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) g[e] = norm_act_grad(xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e]), g[e], relu);
     }
     const f32x4 r = rstd * w * (g - a1 - xh * a2);
     st4(dx + base + i * 4, r);
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(NT) void in_apply_sliced_kernel(const T* __restrict
     v = v * sc + sh;
     if (relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = norm_act(v[e], relu);
     }
     if (residual != nullptr) v += ld4(residual + o);
     st4(y + o, v);
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(NT) void in_bwd_apply_sliced_kernel(const T* __rest
     f32x4 g = ld4(dy + o);
     if (relu) {   // the forward's own x * scale + shift (see in_bwd_stats_kernel)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e])) > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) g[e] = norm_act_grad(xv[e] * (rstd[e] * w[e]) + (bb[e] - mean[e] * rstd[e] * w[e]), g[e], relu);
     }
     const f32x4 r = rstd * w * (g - a1v - xh * a2v);
     st4(dx + o, r);
@@ -536,7 +554,7 @@ __global__ __launch_bounds__(NT) void ln_apply_kernel(const T* __restrict__ x, T
     v = v * *reinterpret_cast<const f32x4*>(scale + q * 4) + *reinterpret_cast<const f32x4*>(shift + q * 4);
     if (relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = norm_act(v[e], relu);
     }
     st4(y + (long long)b * n + i * 4, v);
   }
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_stats_kernel(const T* __restrict__ 
         f32x4 g = ld4(dy + o);
         if (relu) {   // the branch the forward took: x * (inv * gamma) + (beta - mean * inv * gamma), bit for bit (ln_apply)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e])) > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < 4; ++e) g[e] = norm_act_grad(xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e]), g[e], relu);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const T* __restrict__ 
     f32x4 g = ld4(dy + base + i * 4);
     if (relu) {   // the forward's own expression (see ln_bwd_stats_kernel)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e])) > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 4; ++e) g[e] = norm_act_grad(xv[e] * (inv * gm[e]) + (bt[e] - mean * inv * gm[e]), g[e], relu);
     }
     const f32x4 r = (g * gm - c1) * inv - xn * c2;
     st4(dx + base + i * 4, r);

@@ -156,7 +156,7 @@ def launch_transform(arrays, masks, draws, device, stream, ring=None, pool=None)
     """Stage decoded uint8 images (H,W,3) [and masks (H,W)] in pinned memory, upload them with one async copy
     and run the device transform on `stream`.  Returns (outputs, ready event, buffers to keep alive until the
     event): outputs = images (B,3,h,w) channels_last, or (images, masks (B,1,h,w)).  ring: _StagingRing to take the
-    pinned buffer from (else a fresh one); pool: executor that copies the images into it in parallel."""
+    pinned buffer from (else a fresh one); pool: unused (the copies run in the calling thread, see below)."""
     lib = _lib.load()
     B = len(arrays)
     th, tw = draws[0][5], draws[0][6]
@@ -179,13 +179,13 @@ def launch_transform(arrays, masks, draws, device, stream, ring=None, pool=None)
     def put(a, o):
         sv[o:o + a.nbytes] = a.reshape(-1)     # a large contiguous copy: numpy drops the GIL for it
 
+    # The copies run HERE, in the producer thread: the decode pool's queue already holds the files of the next `ahead`
+    # batches, and copies submitted behind them made every upload wait for all of that decode work (a latency bubble per
+    # batch).  2 B contiguous memcpys of a few MB each, with the GIL released, cost less than that wait.  (`pool` is kept in
+    # the signature for callers that pass it.)
     jobs = list(zip(arrays, offs)) + (list(zip(masks, moffs)) if masks is not None else [])
-    if pool is not None and len(jobs) > 1:
-        for f in [pool.submit(put, a, o) for a, o in jobs]:
-            f.result()
-    else:
-        for a, o in jobs:
-            put(a, o)
+    for a, o in jobs:
+        put(a, o)
     ksize = 3
     for a, d in zip(arrays, draws):
         ksize = max(ksize, lib.munit_image_ksize(a.shape[0], d[1]), lib.munit_image_ksize(a.shape[1], d[2]))

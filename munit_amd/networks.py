@@ -191,14 +191,13 @@ class Conv2dBlock(nn.Module):
                 raise NotImplementedError("munit_amd: residual add needs a normalised block")
             return y
         y = self.conv(x, self.pad.padding, self.pad.kind, upsample, "none", out_dtype=out_dtype, link=link_open)
-        relu = self.activation == "relu"
+        act = self.activation      # fused into the norm kernels' apply pass (forward and backward): none / relu / lrelu / tanh
         if isinstance(self.norm, LayerNorm):
             assert residual is None
-            y = self.norm(y, relu)
+            y = self.norm(y, act)
         else:
-            y = self.norm(y, relu, residual, link_close)
-        if self.activation in ("lrelu", "tanh"):      # the norm kernels fuse ReLU only: any other pair runs the activation on its own
-            y = ops.activation(y, self.activation)
+            assert residual is None or act == "none"      # out += residual closes a block whose activation is 'none' (networks.py:611-624)
+            y = self.norm(y, act, residual, link_close)
         return y
 
 
@@ -316,9 +315,17 @@ class ContentEncoder(nn.Module):
         # activations -- and through the content code everything the decoder computes up to its 3-channel image head --
         # live in HBM.  None = fp32, the reference's.  The 3-channel input image is always fp32.
         self.store_dtype = None
+        # data-parallel exchange (trainer.GradExchange): when `keep_trunk_in` is set, the tensor entering the residual trunk is
+        # left in `trunk_in` for the caller to hook (its gradient exists once every trunk weight gradient of this pass has been
+        # issued); the caller takes it and clears both
+        self.keep_trunk_in = False
+        self.trunk_in = None
 
     def forward(self, x):
+        last = len(self.model) - 1
         for i, m in enumerate(self.model):
+            if i == last and self.keep_trunk_in:
+                self.trunk_in = x
             x = m(x, out_dtype=self.store_dtype) if (i == 0 and self.store_dtype is not None) else m(x)
         return x
 
@@ -385,7 +392,25 @@ def _num_adain_params(model):
     return n
 
 
-class AdaINGen(nn.Module):
+class _ApplyRefreshesImages:
+    """nn.Module.apply with a tail: the reference's weights_init writes through `m.weight.data` (utils.py:1093-1115), which
+    bumps no version counter, so the prepared weight images kept with the parameters (ops._prepared) would go stale unseen.
+    After any apply() on a network or on the trainer the optimizers that own its parameters rebuild their images (one launch
+    each; nothing happens before the parameters are bound to a device buffer)."""
+
+    def apply(self, fn):
+        out = super().apply(fn)
+        opts = {}
+        for p in self.parameters():
+            o = getattr(p, "_munit_opt", None)
+            if o is not None:
+                opts[id(o)] = o
+        for o in opts.values():
+            o.invalidate_prepared()
+        return out
+
+
+class AdaINGen(_ApplyRefreshesImages, nn.Module):
     """networks.py:170-254."""
 
     def __init__(self, input_dim, params):
@@ -424,7 +449,7 @@ class AdaINGen(nn.Module):
         return self.mlp(style)
 
 
-class AdaINGen_double(nn.Module):
+class AdaINGen_double(_ApplyRefreshesImages, nn.Module):
     """networks.py:262-388: one shared style encoder, two content encoders / decoders / MLPs."""
 
     def __init__(self, input_dim, params):
@@ -494,7 +519,7 @@ class AdaINGen_double(nn.Module):
 BATCH_DIS_PAIR = os.environ.get("MUNIT_NO_BATCH_DIS_PAIR", "0") != "1"
 
 
-class MsImageDis(nn.Module):
+class MsImageDis(_ApplyRefreshesImages, nn.Module):
     """networks.py:20-115 (LSGAN branch; nsgan hard-codes .cuda() BCE in the reference and is
     not on the configs' path)."""
 

@@ -515,6 +515,19 @@ def linear(x, weight, bias=None, act="none"):
     return y.reshape(b, n)
 
 
+_NORM_ACT = {False: 0, True: 1, None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
+
+
+def _norm_act(relu):
+    """Activation fused behind a normalisation (networks.py:668-681, 695-701 pair any norm with any activation): the norm
+    kernels take MUNIT_ACT_* in their `relu` argument -- 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh.  Accepts the historical
+    bool or the Conv2dBlock's activation name."""
+    try:
+        return _NORM_ACT[relu]
+    except KeyError:
+        raise NotImplementedError("munit_amd: activation %r after a normalisation layer" % (relu,))
+
+
 class _InstNorm(Function):
     @staticmethod
     @_guarded
@@ -536,15 +549,16 @@ class _InstNorm(Function):
             residual = nhwc(residual)
             if residual.dtype != x.dtype:
                 raise RuntimeError("munit_amd.instance_norm: residual must have the input's dtype")
+        relu = _norm_act(relu)
         fn = lib.munit_instnorm_fwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_instnorm_fwd
-        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(adain), ld, w_off, b_off, _p(residual), int(relu),
+        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(adain), ld, w_off, b_off, _p(residual), relu,
                       c_float(eps), _p(ws), ws.numel(), _stream()), "instnorm_fwd")
         ctx.cfg = (w_off, b_off, relu, ld)
         ctx.has_res = residual is not None
         ctx.link = link if residual is not None else None
         ctx.sink, ctx.sink_first = (sink, sink_first) if adain is not None else (None, False)
         ctx.save_for_backward(x, stats, adain)
-        if MASK_SINK is not None and relu:
+        if MASK_SINK is not None and relu in (1, 2):      # ReLU / LeakyReLU: the sign of the output is the branch taken
             if residual is not None:
                 raise RuntimeError("munit_amd: kink recording needs relu and residual on different layers")
             MASK_SINK.append(y > 0)
@@ -572,7 +586,7 @@ class _InstNorm(Function):
             dy = dy.to(x.dtype)
         fn = lib.munit_instnorm_bwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_instnorm_bwd
         _lib.check(fn(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(adain), _p(d_adain), ld, w_off, b_off,
-                      int(relu), _p(ws), ws.numel(), _stream()), "instnorm_bwd")
+                      relu, _p(ws), ws.numel(), _stream()), "instnorm_bwd")
         if sink is not None:
             if ctx.sink_first:
                 sink.buf = None                      # handed to autograd: the buffer is complete
@@ -585,7 +599,8 @@ class _InstNorm(Function):
 
 
 def instance_norm(x, relu=False, residual=None, eps=1e-5, link=None):
-    """nn.InstanceNorm2d(affine=False) (networks.py:657) [+ReLU] [+residual].  link: see ResidualLink."""
+    """nn.InstanceNorm2d(affine=False) (networks.py:657) [+activation: bool ReLU or "relu" / "lrelu" / "tanh" / "none"]
+    [+residual].  link: see ResidualLink."""
     return _InstNorm.apply(x, None, residual, 0, 0, relu, eps, link)
 
 
@@ -606,14 +621,15 @@ class _LayerNorm(Function):
         y = torch.empty_like(x)
         stats = torch.empty((b, 2), device=x.device, dtype=torch.float32)
         ws = workspace(lib.munit_layernorm_workspace_bytes(b, h * w, c), x.device)
+        relu = _norm_act(relu)
         fn = lib.munit_layernorm_fwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_layernorm_fwd
-        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(gamma), _p(beta), int(relu), c_float(eps), _p(ws),
+        _lib.check(fn(_p(x), _p(y), _p(stats), b, h * w, c, _p(gamma), _p(beta), relu, c_float(eps), _p(ws),
                       ws.numel(), _stream()), "layernorm_fwd")
         ctx.cfg = (relu, eps)
         ctx.gbuf = getattr(gamma, "_munit_grad", None)
         ctx.bbuf = getattr(beta, "_munit_grad", None)
         ctx.save_for_backward(x, stats, gamma, beta)
-        if MASK_SINK is not None and relu:
+        if MASK_SINK is not None and relu in (1, 2):
             MASK_SINK.append(y > 0)
         return y
 
@@ -637,7 +653,7 @@ class _LayerNorm(Function):
             dy = dy.to(x.dtype)
         fn = lib.munit_layernorm_bwd_bf16 if x.dtype == torch.bfloat16 else lib.munit_layernorm_bwd
         _lib.check(fn(_p(x), _p(dy), _p(stats), _p(dx), b, h * w, c, _p(gamma), _p(beta), _p(dgamma), _p(dbeta),
-                      c_float(1.0 if into else 0.0), int(relu), c_float(eps), _p(ws), ws.numel(), _stream()),
+                      c_float(1.0 if into else 0.0), relu, c_float(eps), _p(ws), ws.numel(), _stream()),
                    "layernorm_bwd")
         if into or not want:
             return dx, None, None, None, None
@@ -646,7 +662,7 @@ class _LayerNorm(Function):
 
 
 def layer_norm(x, gamma, beta, relu=False, eps=1e-5):
-    """MUNIT's LayerNorm (networks.py:862-878) [+ReLU]."""
+    """MUNIT's LayerNorm (networks.py:862-878) [+activation, see instance_norm]."""
     return _LayerNorm.apply(x, gamma, beta, relu, eps)
 
 
@@ -789,42 +805,6 @@ class _MseConst(Function):
 def mse_const(x, target):
     """LSGAN term torch.mean((x - target) ** 2) (networks.py:91,109)."""
     return _MseConst.apply(x, float(target))
-
-
-class _Act(Function):
-    """LeakyReLU(0.2) / tanh as a layer of its own: the activation of a Conv2dBlock that has a normalisation in front of it
-    (scripts/networks.py:695-701 applies norm, then activation, whatever the pair).  The norm kernels fuse ReLU only -- the
-    configs of the reference never ask for another pair (generator: relu, discriminator: lrelu without a norm), so this path
-    is correctness, not speed: the forward is torch's element-wise kernel, the backward munit_act_bwd on the saved output."""
-
-    @staticmethod
-    def forward(ctx, x, act, slope):
-        _require(x, "activation input", bf16_ok=True)
-        x = nhwc(x)
-        if act == "lrelu":
-            y = torch.nn.functional.leaky_relu(x, slope)
-        elif act == "tanh":
-            y = torch.tanh(x)
-        else:
-            raise NotImplementedError("munit_amd: activation %r after a normalisation layer" % act)
-        y = nhwc(y)
-        if MASK_SINK is not None and act == "lrelu":
-            MASK_SINK.append(y > 0)
-        ctx.save_for_backward(y)
-        ctx.act, ctx.slope = act, slope
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        if y.dtype != torch.float32:      # bf16 storage: munit_act_bwd is an fp32 kernel; same formula on torch's kernels
-            d = torch.where(y > 0, 1.0, ctx.slope) if ctx.act == "lrelu" else 1.0 - y.float() * y.float()
-            return nhwc((dy.float() * d).to(y.dtype)), None, None
-        return act_bwd_raw(ctx.act, ctx.slope, y, nhwc(dy)), None, None
-
-
-def activation(x, act, slope=0.2):
-    return _Act.apply(x, act, float(slope))
 
 
 class _ScalarSum(Function):

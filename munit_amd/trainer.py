@@ -26,7 +26,7 @@ import torch.nn as nn
 from torch.optim import Optimizer
 
 from . import ops
-from .networks import AdaINGen, AdaINGen_double, ContentEncoder, InstanceNorm2d, MsImageDis
+from .networks import AdaINGen, AdaINGen_double, ContentEncoder, InstanceNorm2d, MsImageDis, _ApplyRefreshesImages
 from .utils import get_model_list, get_scheduler, normalize_config, weights_init
 
 
@@ -223,76 +223,101 @@ def dp_world():
     return world if (world > 1 or FORCE_ALLREDUCE) else 0
 
 
+def comm_stream(dev):
+    """The communication stream of a device (one per process and device): early gradient exchanges, the deferred
+    discriminator exchange + optimizer step."""
+    key = (dev.type, dev.index)
+    if key not in GradExchange._comm:
+        GradExchange._comm[key] = torch.cuda.Stream(device=dev)
+    return GradExchange._comm[key]
+
+
 class GradExchange:
-    """All-reduce (mean) of a flat gradient buffer in two parts.
+    """All-reduce (mean) of a flat gradient buffer in stages that start INSIDE the backward pass.
 
     Every generator weight is used by several sub-graph calls (4 encodes, 6 decodes per gen_update), so a gradient is final only
-    when the LAST backward pass through its module has run.  Backward replays the forward in reverse: the decoders' and the
-    MLPs' last use is the pair of decodes right after the first encodes, so their gradients -- `early`, about half of the flat
-    buffer -- are final when the gradients of the first encodes' outputs (c_a, c_b, s_a', s_b') have been formed, while the
-    backward of those two encodes (about 8 % of the backward pass) is still to come.  `arm(tensors)` hooks those tensors; when
-    the last hook fires, a communication stream is ordered behind everything enqueued so far on the producing streams and the
-    early ranges are all-reduced from it, asynchronously.  `finish()` (after backward, on the caller's stream) reduces the rest,
-    waits for the early part and scales by 1 / world.
+    when the LAST backward pass through its module has run.  Backward replays the forward in reverse:
+      stage 1 -- the decoders' and the MLPs' last use is the pair of decodes right after the first encodes, so their gradients
+        (about half of the flat buffer) are final when the gradients of the first encodes' outputs (c_a, c_b, s_a', s_b'; with
+        guided == 0 also of the sampled styles, whose MLP passes have no other tensor downstream) have been formed, while the
+        backward of those two encodes (about 8 % of the backward pass) is still to come;
+      stage 2 -- inside that last stretch the content encoders' residual trunks (7/8 of an encoder's weights) finish first: their
+        gradients are final when the gradient of the tensor ENTERING the trunk has been formed in both first encodes, while
+        the down-sampling layers, the 7x7 first layers and the style encoder are still running.
+    `arm(ranges, tensors)` declares a stage: it hooks the tensors, and when the last hook fires a communication stream is
+    ordered behind everything enqueued so far on the producing streams (every kernel that writes the ranges has been enqueued
+    by then: a node's backward-weight launch precedes the gradient it returns) and the ranges are all-reduced from it,
+    asynchronously.  `finish()` (after backward, on the caller's stream) reduces what no stage covered, waits for the stages
+    and scales by 1 / world.
 
-    Every rank issues the same collectives in the same order (early ranges in buffer order, then the rest in buffer order).
-    Each element is summed over the ranks exactly once either way; with two ranks the result is bitwise the single all-reduce's
-    (tests), with more ranks it can differ in the last bit where the ring's chunk boundaries move -- as between any two bucket
-    layouts."""
+    Every rank issues the same collectives in the same order (the autograd engine's order is a function of the graph; ranges
+    of a stage in buffer order, then the rest in buffer order).  Each element is summed over the ranks exactly once either
+    way; with two ranks the result is bitwise the single all-reduce's (tests), with more ranks it can differ in the last bit
+    where the ring's chunk boundaries move -- as between any two bucket layouts."""
 
     _comm = {}
 
-    def __init__(self, flat, early, world, streams=()):
+    def __init__(self, flat, world, streams=()):
         self.flat, self.world = flat, world
-        self.early = [r for r in early if r[1] > r[0]]
+        self.streams = [s for s in streams if s is not None]
+        self.stages, self.works = [], []
+
+    @property
+    def fired(self):
+        return any(st["fired"] for st in self.stages)
+
+    def arm(self, ranges, tensors):
+        """A stage without a tensor that requires a gradient (or without elements) is dropped: finish() sends its ranges."""
+        ranges = [tuple(r) for r in ranges if r[1] > r[0]]
+        ts = [t for t in tensors if torch.is_tensor(t) and t.requires_grad]
+        if not ranges or not ts:
+            return self
+        for a, b in ranges:
+            for st in self.stages:
+                assert all(b <= c or d <= a for c, d in st["ranges"]), "GradExchange: stages must not overlap"
+        st = {"ranges": ranges, "pending": len(ts), "fired": False}
+        self.stages.append(st)
+        for t in ts:
+            t.register_hook(lambda grad, st=st: self._hook(st))
+        return self
+
+    def _hook(self, st):
+        st["pending"] -= 1
+        if st["pending"] == 0:
+            self._launch(st)
+        return None
+
+    def _launch(self, st):
+        import torch.distributed as dist
+        st["fired"] = True
+        if self.flat.is_cuda:
+            comm = comm_stream(self.flat.device)
+            for s in self.streams:            # everything that writes the stage's ranges has been enqueued on these by now
+                ops.stream_wait(comm, s)
+            with torch.cuda.stream(comm):
+                for a, b in st["ranges"]:
+                    self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
+        else:
+            for a, b in st["ranges"]:
+                self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
+
+    @property
+    def rest(self):
+        """What no fired stage covers, in buffer order."""
+        done = sorted(r for st in self.stages if st["fired"] for r in st["ranges"])
         rest, pos = [], 0
-        for a, b in self.early:
+        for a, b in done:
             if a > pos:
                 rest.append((pos, a))
             pos = b
-        if pos < flat.numel():
-            rest.append((pos, flat.numel()))
-        self.rest = rest
-        self.streams = [s for s in streams if s is not None]
-        self.works, self.pending, self.fired = [], 0, False
-
-    def arm(self, tensors):
-        ts = [t for t in tensors if torch.is_tensor(t) and t.requires_grad]
-        self.pending = len(ts)
-        for t in ts:
-            t.register_hook(self._hook)
-        return self
-
-    def _hook(self, grad):
-        self.pending -= 1
-        if self.pending == 0:
-            self._launch_early()
-        return None
-
-    def _launch_early(self):
-        import torch.distributed as dist
-        self.fired = True
-        if self.flat.is_cuda:
-            dev = self.flat.device
-            key = (dev.type, dev.index)
-            if key not in GradExchange._comm:
-                GradExchange._comm[key] = torch.cuda.Stream(device=dev)
-            comm = GradExchange._comm[key]
-            for st in self.streams:           # everything that writes the early ranges has been enqueued on these by now
-                ops.stream_wait(comm, st)
-            with torch.cuda.stream(comm):
-                for a, b in self.early:
-                    self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
-        else:
-            for a, b in self.early:
-                self.works.append(dist.all_reduce(self.flat[a:b], async_op=True))
+        if pos < self.flat.numel():
+            rest.append((pos, self.flat.numel()))
+        return rest
 
     def finish(self):
         """Call on the stream that holds the complete gradient (after backward and the joins of the producing streams)."""
         import torch.distributed as dist
-        if not self.fired:                    # hooks never fired (no tensor required grad): everything goes now
-            self.rest, self.early = [(0, self.flat.numel())], []
-        for a, b in self.rest:
+        for a, b in self.rest:                # a stage whose hooks never fired (no tensor required grad) goes now
             dist.all_reduce(self.flat[a:b])
         for w in self.works:
             w.wait()                          # on a device: the caller's stream waits for the communication stream
@@ -365,7 +390,7 @@ class _Branches:
                 t.record_stream(self.main)
 
 
-class MUNIT_Trainer(nn.Module):
+class MUNIT_Trainer(_ApplyRefreshesImages, nn.Module):
     def __init__(self, hyperparameters):
         super(MUNIT_Trainer, self).__init__()
         hyperparameters = normalize_config(hyperparameters)
@@ -450,6 +475,11 @@ class MUNIT_Trainer(nn.Module):
         self.dis_b.apply(weights_init("gaussian"))
 
         self._consts = {}
+        # deferred discriminator exchange + step (data parallel, _defer_dis_step)
+        self._dis_pending, self._dis_event, self._dis_waited = None, None, set()
+        for d in (self.dis_a, self.dis_b):
+            d.register_forward_pre_hook(self._wait_dis)
+            d.register_state_dict_pre_hook(self._wait_dis)
         self._bind(torch.device("cpu"))
 
     # ------------------------------------------------------------------------------------
@@ -478,8 +508,12 @@ class MUNIT_Trainer(nn.Module):
         gens = [self.gen] if self.gen_state == 1 else [self.gen_a, self.gen_b]
         early = {id(p) for g in gens for n, p in g.named_parameters() if n.startswith("dec") or n.startswith("mlp")}
         self._early_ranges = self.gen_opt.ranges_of(lambda p: id(p) in early)
+        # ... and of the content encoders' residual trunks (final before the first encodes' down-sampling layers run backward)
+        trunk = {id(p) for k in (1, 2) for p in self._content_enc(k).model[-1].parameters()}
+        self._trunk_ranges = self.gen_opt.ranges_of(lambda p: id(p) in trunk)
 
     def _apply(self, fn, *args, **kwargs):
+        self._settle_dis()
         out = super()._apply(fn, *args, **kwargs)
         p = next(self.dis_a.parameters())
         self._bind(p.device)
@@ -521,6 +555,22 @@ class MUNIT_Trainer(nn.Module):
         if self.gen_state == 1:
             return self.gen.encode(x, k)
         return (self.gen_a if k == 1 else self.gen_b).encode(x)
+
+    def _content_enc(self, k):
+        if self.gen_state == 1:
+            return self.gen.enc1_content if k == 1 else self.gen.enc2_content
+        return (self.gen_a if k == 1 else self.gen_b).enc_content
+
+    def _enc_keep(self, x, k):
+        """encode, also returning the tensor that enters the content encoder's residual trunk (GradExchange stage 2)."""
+        enc = self._content_enc(k)
+        enc.keep_trunk_in = True
+        try:
+            c, s = self._enc(x, k)
+            t = enc.trunk_in
+        finally:
+            enc.keep_trunk_in, enc.trunk_in = False, None
+        return c, s, t
 
     def _dec(self, c, s, k):
         if self.gen_state == 1:
@@ -570,6 +620,8 @@ class MUNIT_Trainer(nn.Module):
         fwd_key = self._fwd_key(x_a, x_b)      # of the caller's tensors (the layout conversion below may copy)
         x_a, x_b = ops.nhwc(x_a), ops.nhwc(x_b)
 
+        world = dp_world()
+        overlap = bool(world and OVERLAP_EXCHANGE)      # stages of the gradient exchange start inside backward (GradExchange)
         d_params = list(self.dis_a.parameters()) + list(self.dis_b.parameters())
         for p in d_params:  # D weight gradients made here would be discarded (trainer.py:1145)
             p.requires_grad_(False)
@@ -579,9 +631,13 @@ class MUNIT_Trainer(nn.Module):
             cached, self._fwd_cache = self._fwd_cache, None
             reuse = (cached is not None and self.guided == 1 and cached[0] == fwd_key)
             self.fwd_reused = reuse
+            trunk_a = trunk_b = None
             if reuse:      # the forward dis_update just ran on these tensors with these generator weights
                 c_a, s_a_prime, c_b, s_b_prime, x_ba_kept, x_ab_kept = cached[1]
                 br.adopt(c_a, s_a_prime, c_b, s_b_prime, x_ba_kept, x_ab_kept)
+            elif overlap:  # also keep the tensors entering the residual trunks: their gradients open stage 2 of the exchange
+                c_a, s_a_prime, trunk_a = br.run(0, lambda: self._enc_keep(x_a, 1))
+                c_b, s_b_prime, trunk_b = br.run(1, lambda: self._enc_keep(x_b, 2))
             else:
                 c_a, s_a_prime = br.run(0, lambda: self._enc(x_a, 1))
                 c_b, s_b_prime = br.run(1, lambda: self._enc(x_b, 2))
@@ -590,6 +646,14 @@ class MUNIT_Trainer(nn.Module):
             x_b_recon = br.run(1, lambda: self._dec(c_b, s_b_prime, 2))
             if self.guided == 0:
                 s_a_use, s_b_use = s_a.to(dev), s_b.to(dev)
+                if overlap:
+                    # The MLP passes over the sampled styles have no hooked tensor downstream: without a gradient of their own
+                    # the exchange's stage 1 would rely on the autograd engine running them before the first decodes' nodes (it
+                    # does -- higher sequence numbers first -- but that is an implementation detail).  With requires_grad the
+                    # styles' gradients are formed at the END of those MLP passes' backward and stage 1 waits for them.  Costs a
+                    # (B, style_dim) backward-data; no parameter gradient changes.
+                    s_a_use.requires_grad_(True)
+                    s_b_use.requires_grad_(True)
             elif self.guided == 1:
                 s_a_use, s_b_use = s_a_prime, s_b_prime
             else:
@@ -649,16 +713,20 @@ class MUNIT_Trainer(nn.Module):
                       (hp["recon_x_cyc_w"], self.loss_gen_cycrecon_x_b)]
         self.loss_gen_total = ops.weighted_sum([t.detach() for _, t in pairs], [w for w, _ in pairs])
         live = [(w, t) for w, t in pairs if w != 0 and t.requires_grad]
-        world = dp_world()
         xch = None
-        if world and OVERLAP_EXCHANGE:
-            # the decoder / MLP half of the flat gradient is exchanged while the first encodes' backward still runs
+        if overlap:
+            # the decoder / MLP half of the flat gradient is exchanged while the first encodes' backward still runs, the content
+            # encoders' residual trunks while their down-sampling and first layers (and the style encoder) still run
             streams = [torch.cuda.current_stream(dev)] if dev.type == "cuda" else []
             if br.enabled:
                 streams += list(br.s)
             if dev.type == "cuda" and ops.SIDE_STREAM_WGRAD:
                 streams.append(ops._side_stream(dev))
-            xch = GradExchange(self.gen_opt.flat_g, self._early_ranges, world, streams).arm([c_a, c_b, s_a_prime, s_b_prime])
+            xch = GradExchange(self.gen_opt.flat_g, world, streams)
+            xch.arm(self._early_ranges, [c_a, c_b, s_a_prime, s_b_prime] + ([s_a_use, s_b_use] if self.guided == 0 else []))
+            if trunk_a is not None and trunk_b is not None:
+                xch.arm(self._trunk_ranges, [trunk_a, trunk_b])
+            self.last_exchange = xch     # introspection (tests): which stages fired
         torch.autograd.backward([t for _, t in live], [self._const(w, dev) for w, _ in live])
         br.join()                        # the backward pass ran on the branch streams its nodes were recorded on
         ops.join_side_streams()          # backward-weight kernels run on a side stream
@@ -676,6 +744,7 @@ class MUNIT_Trainer(nn.Module):
     def dis_update(self, x_a, x_b, hyperparameters, comet_exp=None):
         ops.set_compute(self.precision)
         hp = hyperparameters
+        self._settle_dis()
         self.dis_opt.zero_grad()
         s_a = torch.randn(x_a.size(0), self.style_dim, 1, 1)
         s_b = torch.randn(x_b.size(0), self.style_dim, 1, 1)
@@ -709,9 +778,55 @@ class MUNIT_Trainer(nn.Module):
         torch.autograd.backward([self.loss_dis_a, self.loss_dis_b], [w, w])
         br.join()
         ops.join_side_streams()
-        self._all_reduce_mean(self.dis_opt.flat_g)
-        self.dis_opt_step()
+        if dp_world() and OVERLAP_EXCHANGE and dev.type == "cuda":
+            self._defer_dis_step(dev)
+        else:
+            self._all_reduce_mean(self.dis_opt.flat_g)
+            self.dis_opt_step()
         self._log(comet_exp, ("loss_dis_b", "loss_dis_a"))
+
+    # ---- data parallel: the discriminator exchange beside the next generator forward ---------------------------------
+    def _defer_dis_step(self, dev):
+        """The all-reduce of the discriminator gradient (66 MB), its 1 / world scale and the discriminator's optimizer step
+        (Adam + the refresh of the prepared weight images) are enqueued on the communication stream, behind the backward pass
+        that just ended on the caller's stream.  The caller's stream goes on: in the reference's iteration the next thing
+        is gen_update (scripts/train.py:182-187), whose first ~15 ms -- two encodes, four decodes -- touch no discriminator
+        weight, so the exchange runs beside them.  Whatever reads or writes the discriminators next waits for the recorded event
+        (`_wait_dis`: MsImageDis.forward through a pre-hook, dis_update, save / resume / state_dict)."""
+        import torch.distributed as dist
+        comm = comm_stream(dev)
+        ops.stream_wait(comm, torch.cuda.current_stream(dev))
+        world = dp_world()
+        with torch.cuda.stream(comm):
+            dist.all_reduce(self.dis_opt.flat_g)          # RCCL is ordered behind, and hands back to, the CURRENT stream = comm
+            if world > 1:
+                ops.scale_(self.dis_opt.flat_g, 1.0 / world)
+            self.dis_opt_step()
+            ev = self._dis_event
+            if ev is None:
+                ev = self._dis_event = torch.cuda.Event()
+            ev.record(comm)
+        self._dis_pending = ev
+
+    def _wait_dis(self, *_):
+        """Order the current stream behind a deferred discriminator step (no-op when none is pending on this stream: every
+        stream that reaches the discriminators waits once)."""
+        ev = self._dis_pending
+        if ev is None:
+            return
+        st = torch.cuda.current_stream(self.dis_opt.flat_p.device)
+        key = st.cuda_stream
+        if key in self._dis_waited:
+            return
+        st.wait_event(ev)
+        self._dis_waited.add(key)
+
+    def _settle_dis(self):
+        """A new discriminator update (or a host-side reader) is about to start: the caller's stream waits, nothing pends."""
+        if self._dis_pending is not None:
+            self._wait_dis()
+            self._dis_pending = None
+        self._dis_waited = set()
 
     def _fwd_key(self, x_a, x_b):
         """Identity of a generator forward: the input tensors (storage, layout, in-place version) and the state of the
@@ -793,6 +908,7 @@ class MUNIT_Trainer(nn.Module):
         return {k: v.detach().clone(memory_format=torch.contiguous_format).cpu() for k, v in sd.items()}
 
     def save(self, snapshot_dir, iterations):
+        self._settle_dis()
         gen_name = os.path.join(snapshot_dir, "gen_%08d.pt" % (iterations + 1))
         dis_name = os.path.join(snapshot_dir, "dis_%08d.pt" % (iterations + 1))
         opt_name = os.path.join(snapshot_dir, "optimizer.pt")
@@ -805,6 +921,7 @@ class MUNIT_Trainer(nn.Module):
         torch.save({"gen": self.gen_opt.state_dict(), "dis": self.dis_opt.state_dict()}, opt_name)
 
     def resume(self, checkpoint_dir, hyperparameters):
+        self._settle_dis()
         last_model_name = get_model_list(checkpoint_dir, "gen")
         state_dict = torch.load(last_model_name, map_location="cpu", weights_only=True)
         if self.gen_state == 0:
@@ -822,5 +939,7 @@ class MUNIT_Trainer(nn.Module):
         self.gen_opt.load_state_dict(state_dict["gen"])
         self.dis_scheduler = get_scheduler(self.dis_opt, hyperparameters, iterations)
         self.gen_scheduler = get_scheduler(self.gen_opt, hyperparameters, iterations)
+        self.gen_opt.invalidate_prepared()      # whatever wrote the weights, the prepared images follow them
+        self.dis_opt.invalidate_prepared()
         print("Resume from iteration %d" % iterations)
         return iterations

@@ -237,7 +237,8 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
         d_ref = oracle(lambda: orc.dis_update(ox[0], ox[1], sa, sb), km)
         for (n, p), g in zip(dnames, d_ref):
             if float(g.abs().max()) < 1e-7:      # conv bias ahead of an instance norm (dis norm 'in'): mathematically zero
-                assert float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
+                rep["zero_grad_abs"] = max(rep.get("zero_grad_abs", 0.0), float(p._munit_grad.abs().max()))
+                assert not check or float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
                 null.add(n)
                 continue
             gc.add("dis." + n, p._munit_grad, g, check)
@@ -278,7 +279,8 @@ def run_step_parity(size=64, batch=2, gen_state=1, iters=1, device="cuda:0", ora
             # gradients that are mathematically zero (conv bias ahead of an instance norm)
             # hold only rounding noise on both sides
             if gmax < 1e-7:
-                assert float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
+                rep["zero_grad_abs"] = max(rep.get("zero_grad_abs", 0.0), float(p._munit_grad.abs().max()))
+                assert not check or float(p._munit_grad.abs().max()) < 1e-3, ("zero grad", n)
                 null.add(n)
                 continue
             gc.add("gen." + n, p._munit_grad, g, check)

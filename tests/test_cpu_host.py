@@ -269,25 +269,38 @@ early = [(300, 520), (700, 1000)]                        # two ranges, as gen_st
 # serial form: one all-reduce of the whole buffer
 serial = grad.clone()
 T.MUNIT_Trainer._all_reduce_mean(serial)
-# overlapped form: the early ranges go out from a tensor hook in the middle of a backward pass, the rest afterwards
+# overlapped form: stage 1 (the early ranges) goes out from a tensor hook in the middle of a backward pass, stage 2 (the "residual
+# trunk" of the encoder) from a hook further down, the rest afterwards
 flat = grad.clone()
 enc_w = torch.ones(4, requires_grad=True)
+trunk_w = torch.ones(4, requires_grad=True)
 dec_w = torch.ones(4, requires_grad=True)
-c = enc_w * 3.0                                           # "content code": its gradient is formed after the decoder's
+h = enc_w * 2.0                                           # "tensor entering the trunk": its gradient is formed after the trunk's
+c = h * trunk_w                                           # "content code": its gradient is formed after the decoder's
 fired_at = []
-xch = T.GradExchange(flat, early, T.dp_world()).arm([c])
-enc_w.register_hook(lambda g_: fired_at.append(("enc", xch.fired)))
+trunk = [(100, 260)]
+xch = T.GradExchange(flat, T.dp_world()).arm(early, [c]).arm(trunk, [h])
+trunk_w.register_hook(lambda g_: fired_at.append(("trunk", [st["fired"] for st in xch.stages])))
+enc_w.register_hook(lambda g_: fired_at.append(("enc", [st["fired"] for st in xch.stages])))
 loss = (dec_w * c).sum()
 loss.backward()
-assert xch.fired and fired_at == [("enc", True)], fired_at   # the exchange was launched BEFORE the encoder's gradient existed
-assert xch.rest == [(0, 300), (520, 700)], xch.rest
+# stage 1 was launched BEFORE the trunk's gradient existed, stage 2 BEFORE the encoder's first layer's
+assert fired_at == [("trunk", [True, False]), ("enc", [True, True])], fired_at
+assert xch.rest == [(0, 100), (260, 300), (520, 700)], xch.rest
 xch.finish()
 assert torch.equal(flat, serial), (flat - serial).abs().max()
-# a graph in which no hooked tensor needs a gradient: everything is exchanged in finish()
+# a stage whose tensors need no gradient is dropped: its ranges are exchanged in finish()
 flat2 = grad.clone()
-x2 = T.GradExchange(flat2, early, T.dp_world()).arm([torch.ones(3)])
+x2 = T.GradExchange(flat2, T.dp_world()).arm(early, [torch.ones(3)])
+assert not x2.stages and not x2.fired and x2.rest == [(0, n)]
 x2.finish()
 assert torch.equal(flat2, serial)
+# overlapping stages are a programming error
+try:
+    T.GradExchange(grad.clone(), T.dp_world()).arm(early, [c]).arm([(500, 600)], [c])
+    raise SystemExit("overlap accepted")
+except AssertionError:
+    pass
 other = [torch.zeros(n) for _ in range(2)]
 dist.all_gather(other, grad)
 assert torch.allclose(serial, (other[0] + other[1]) / 2)
@@ -317,7 +330,8 @@ def test_overlapped_gradient_exchange_equals_the_serial_all_reduce_gloo_world2(t
 
 def test_early_exchange_ranges_cover_decoders_and_mlps():
     """The flat-buffer ranges handed to GradExchange are exactly the decoder and MLP parameters (gen_state 1: one contiguous
-    tail of the buffer; gen_state 0: one range per generator), 16-byte aligned."""
+    tail of the buffer; gen_state 0: one range per generator), 16-byte aligned; stage 2's are exactly the residual trunks of the
+    two content encoders (one range each), disjoint from stage 1's."""
     from munit_amd.trainer import MUNIT_Trainer
     for gs, n_ranges in ((1, 1), (0, 2)):
         tr = MUNIT_Trainer(O.default_hp(64, 1, gs))
@@ -332,6 +346,15 @@ def test_early_exchange_ranges_cover_decoders_and_mlps():
             assert inside == late, (n, off, r)
         if gs == 1:
             assert r[0][1] == tr.gen_opt._total
+        t = tr._trunk_ranges
+        assert len(t) == 2 and all(a % 4 == 0 and b % 4 == 0 for a, b in t), t
+        for n, p, off in zip(names, tr.gen_opt._plist, offs):
+            in_trunk = ("content.model.3." in n)          # config_256.yaml: two down-samplings -> the ResBlocks are model.3
+            inside = any(a <= off and off + p.numel() <= b for a, b in t)
+            assert inside == in_trunk, (n, off, t)
+        assert all(b <= c or d <= a for a, b in t for c, d in r)
+        # 4 blocks x 2 convs x (256 * 256 * 9 + 256) parameters per encoder
+        assert all(b - a == 8 * (256 * 256 * 9 + 256) for a, b in t), t
 
 
 def test_bench_self_launches_ranks_from_a_bare_shell():
@@ -505,3 +528,22 @@ def test_trainer_method_surface_is_the_reference_s():
     sig = inspect.signature(MUNIT_Trainer.gen_update).parameters
     assert sig["comet_exp"].default is None and sig["synth"].default is False and sig["semantic_gt_a"].default is None
 
+
+
+def test_bench_sizes_host_threads_from_the_granted_cpus(monkeypatch):
+    """bench.py's thread pools (the ranks it launches, the CPU-baseline leg) are sized from the CPUs the process may use --
+    affinity mask capped by the cgroup quota, the rule of tests/conftest.usable_cpus -- never from os.cpu_count(), which on
+    the GPU boxes reports 256 for a grant of 16."""
+    import bench
+    from tests.conftest import usable_cpus
+    assert bench.usable_cpus() == usable_cpus()
+    monkeypatch.setattr(os, "cpu_count", lambda: 4096)         # what the box SHOWS must not matter
+    n = bench.usable_cpus()
+    assert n == usable_cpus() and n <= len(os.sched_getaffinity(0))
+    assert bench.host_cores() <= n
+    assert bench.rank_threads(1) == n and bench.rank_threads(8) == max(1, n // 8) and bench.rank_threads(10 * n) == 1
+    monkeypatch.setattr(bench, "cpu_quota", lambda: 3)          # a quota below the affinity mask wins
+    assert bench.usable_cpus() == min(3, len(os.sched_getaffinity(0)))
+    assert bench.rank_threads(2) == max(1, bench.usable_cpus() // 2)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("os.cpu_count()") == 2                     # the docstring and the no-sched_getaffinity fallback of usable_cpus

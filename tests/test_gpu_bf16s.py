@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 BF16_OUT = 8e-3        # bf16 rounding of an output tensor (normalised max)
 SHARP = 3e-5           # fp32 accumulation of exact bf16 products vs fp64
 MODE_TOL = 2e-2        # stated tolerance of the bf16 configuration vs the unrounded oracle
-GRAD_TENSOR_TOL = 6e-2 # step level: relative L2 of EVERY generator gradient tensor, bf16-storage step vs the fp32 step (provisional:
-                       # set from the first measured run)
+GRAD_TENSOR_TOL = 6e-2 # step level: relative L2 of EVERY gradient tensor of a bf16-storage step against the fp64 oracle taking the SAME
+                       # ReLU / LeakyReLU / L1 branches (measured on MI355X: worst 4.0e-2 at 64x64 batch 2, 4.5e-2 at 256x256 batch 1;
+                       # medians 1.6e-2 / 0.9e-2)
 
 
 def dev():
@@ -192,8 +193,7 @@ def test_step_bf16_storage_tracks_fp32_step(size, batch):
         tr.dis_update(x_a, x_b, hp)
         tr.gen_update(x_a, x_b, hp, m_a, m_b)
         names = [n for n in vars(tr) if n.startswith("loss_")]
-        per_tensor = {n: p._munit_grad.detach().clone() for n, p in trainer_named_params(tr)[0]}
-        out[prec] = ({n: float(getattr(tr, n)) for n in names}, tr.gen_opt.flat_g.detach().clone(), img.detach().clone(), per_tensor)
+        out[prec] = ({n: float(getattr(tr, n)) for n in names}, tr.gen_opt.flat_g.detach().clone(), img.detach().clone())
     ops.set_compute("bf16s")
     lf, lb = out["f32"][0], out["bf16s"][0]
     assert set(lf) == set(lb) and len(lf) >= 10
@@ -201,23 +201,15 @@ def test_step_bf16_storage_tracks_fp32_step(size, batch):
         assert abs(lb[n] - lf[n]) <= MODE_TOL * max(abs(lf[n]), 1e-3), (n, lf[n], lb[n])
     assert nerr(out["bf16s"][2], out["f32"][2]) <= MODE_TOL * 2.5     # decoded image: eleven bf16 layers deep
     # the flat generator gradient points the same way (cosine), and is finite everywhere
+    # (Unpinned, bf16 rounding flips ~1 % of the L1 terms' signs and ReLU branches, each a +-1/N jump of a gradient: tensor by
+    # tensor the two steps differ by 0.2 - 0.45 relative L2 at random initialisation -- measured -- although they point the same
+    # way.  The per-tensor bound is therefore taken against the fp64 oracle with the kinks PINNED to the bf16 run:
+    # test_step_bf16_storage_matches_the_pinned_oracle, and config #3's batch is tied to it by
+    # test_config3_batch_gradient_is_the_mean_of_the_per_sample_gradients.)
     gf, gb = out["f32"][1].double(), out["bf16s"][1].double()
     assert torch.isfinite(gb).all()
     cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
     assert cos > 0.98, cos
-    # ... and tensor by tensor: relative L2 of every generator gradient tensor against the fp32 step (bf16 rounding of ~11
-    # layers of activations and of their gradients, plus the ReLU / L1 kinks the two arithmetic modes take differently).
-    # Stated bound GRAD_TENSOR_TOL on every tensor, a quarter of it on the median.
-    rows = []
-    for n, g32 in out["f32"][3].items():
-        if float(g32.abs().max()) < 1e-7:        # conv bias ahead of an instance norm: mathematically zero, noise on both sides
-            continue
-        rows.append((l2err(out["bf16s"][3][n], g32), n))
-    rows.sort(reverse=True)
-    print("bf16s vs f32 per-tensor gradient L2: worst", rows[:3], "median", rows[len(rows) // 2][0])
-    assert len(rows) >= 80
-    assert rows[0][0] <= GRAD_TENSOR_TOL, rows[:5]
-    assert rows[len(rows) // 2][0] <= GRAD_TENSOR_TOL / 4, rows[len(rows) // 2]
 
 
 def test_bf16_storage_two_generators_and_inference():
@@ -275,3 +267,94 @@ def test_bf16_storage_on_another_geometry():
     for n, v in out["f32"].items():
         assert out["bf16s"][n] == out["bf16s"][n] and abs(out["bf16s"][n] - v) <= 3 * MODE_TOL * max(abs(v), 1e-3), (n, v, out["bf16s"][n])
 
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (256, 1)], ids=["64_b2", "256_b1"])
+def test_step_bf16_storage_matches_the_pinned_oracle(size, batch):
+    """One dis_update + gen_update in bf16 storage against the fp64 oracle that takes the bf16 run's own ReLU / LeakyReLU / L1
+    branches (tests/parity.py: both sides then differentiate the same piecewise-linear function, so what remains is the bf16
+    rounding of the trunk's activations and of their gradients): every loss within the mode's 2e-2, EVERY gradient tensor
+    within GRAD_TENSOR_TOL relative L2 (median a quarter of it), Adam moments and weights after the step within the same.  The
+    second case is config #3's resolution at batch 1; its batch of 32 is tied to per-sample steps by the next test."""
+    from tests.parity import run_step_parity
+    rep = run_step_parity(size=size, batch=batch, gen_state=1, iters=1, device="cuda:0", precision="bf16s", check=False)
+    print({k: v for k, v in rep.items() if not isinstance(v, list)}, "loosest:", sorted(rep["grad_kinks"], key=lambda r: -r[2])[:4])
+    assert rep["loss_rel"] <= MODE_TOL, rep["loss_rel"]
+    assert rep["grad_l2"] <= GRAD_TENSOR_TOL and rep["grad_nerr"] <= 1.5 * GRAD_TENSOR_TOL, (rep["grad_l2"], rep["grad_nerr"])
+    assert rep["grad_l2_median"] <= 2.5e-2, rep["grad_l2_median"]
+    assert rep["moment_l2"] <= 2 * GRAD_TENSOR_TOL and rep["weight_abs"] <= 4.0 * 1e-4, (rep["moment_l2"], rep["weight_abs"])
+    # the recorded branches differ from the oracle's own only near the kinks: within the bf16 rounding that eleven layers of
+    # bf16 activations accumulate on a pre-activation (measured 5.1e-2 / 5.6e-2 of the tensor maximum on 0.6 % of the elements)
+    assert rep["kink_worst_rel"] <= 0.1 and rep["kink_disagree_frac"] <= 2e-2, (rep["kink_worst_rel"], rep["kink_disagree_frac"])
+    # biases ahead of an instance norm have a mathematically zero gradient: bf16 noise only
+    assert rep["zero_grad_abs"] <= 2e-2, rep["zero_grad_abs"]
+
+
+def test_config3_batch_statistics_are_the_means_of_the_per_sample_ones():
+    """BASELINE.json config #3 at its own size (256x256, batch 32, bf16 storage), where the fp64 oracle is out of reach: every
+    loss is a batch mean and every normalisation per sample, so the batch-32 dis_update / gen_update must
+    reproduce the MEANS of the 32 batch-1 updates on the same weights -- a kernel that mixes samples or mis-tiles the large
+    batch cannot.  Losses: every loss_* within 2e-3 relative.  Gradients, tensor by tensor: the comparison is UNPINNED between
+    the two batch sizes, and in bf16 storage a rounding that lands differently when the batch is tiled differently is amplified
+    layer by layer into flipped ReLU / L1 branches (measured: median 0.20 relative L2 -- the same signature the bf16-vs-fp32
+    comparison shows; the PINNED per-tensor bound is test_step_bf16_storage_matches_the_pinned_oracle), so the bound here is
+    the one that separates 'same gradient up to flipped kinks' from 'another gradient': relative L2 <= 0.6 and cosine >= 0.8
+    on every tensor (uncorrelated tensors: 1.41 / 0), 1e-2 on the discriminators (fp32 throughout, their inputs bf16-made)."""
+    import bench
+    from munit_amd.trainer import MUNIT_Trainer
+    size, batch = 256, 32
+    data = bench.make_batch(batch, size)
+    hp = bench.bench_hp(size, batch)
+    hp["precision"] = "bf16s"
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(hp)
+    tr.to(dev())
+    g0, d0 = tr.gen_opt.flat_p.detach().clone(), tr.dis_opt.flat_p.detach().clone()
+    gnames, dnames = trainer_named_params(tr)
+    loss_names = None
+
+    def run(sel):
+        nonlocal loss_names
+        x_a, x_b, m_a, m_b = (t[sel].to(dev()) for t in data)
+        with torch.no_grad():       # every run on the initial weights (the optimizers' moments do not enter a gradient)
+            tr.gen_opt.flat_p.copy_(g0)
+            tr.dis_opt.flat_p.copy_(d0)
+        tr.gen_opt.invalidate_prepared()
+        tr.dis_opt.invalidate_prepared()
+        tr.dis_update(x_a, x_b, hp)
+        gd = [p._munit_grad.detach().double().clone() for _, p in dnames]
+        with torch.no_grad():
+            tr.dis_opt.flat_p.copy_(d0)
+        tr.dis_opt.invalidate_prepared()
+        tr.gen_update(x_a, x_b, hp, m_a, m_b)
+        gg = [p._munit_grad.detach().double().clone() for _, p in gnames]
+        if loss_names is None:
+            loss_names = sorted(n for n in vars(tr) if n.startswith("loss_") and torch.is_tensor(getattr(tr, n)))
+        losses = torch.stack([getattr(tr, n).detach().double().reshape(()) for n in loss_names])
+        return gd, gg, losses
+
+    whole = run(list(range(batch)))
+    mean = None
+    for i in range(batch):
+        part = run([i])
+        mean = part if mean is None else ([a + b for a, b in zip(mean[0], part[0])], [a + b for a, b in zip(mean[1], part[1])],
+                                          mean[2] + part[2])
+    lrel = ((whole[2] - mean[2] / batch).abs() / (mean[2] / batch).abs().clamp_min(1e-3)).cpu()
+    print("config #3 losses, batch 32 vs mean of per-sample:", {n: float(v) for n, v in zip(loss_names, lrel)})
+    assert len(loss_names) >= 10 and float(lrel.max()) <= 2e-3, (loss_names, lrel)
+    rows = [[], []]
+    for k, names in ((0, dnames), (1, gnames)):
+        for (n, _), w, m in zip(names, whole[k], mean[k]):
+            assert torch.isfinite(w).all()
+            # conv biases ahead of an instance norm / AdaIN: mathematically zero, bf16 noise on both sides
+            if k == 1 and n.endswith("conv.bias") and ("_content." in n or ".model.0.model." in n):
+                continue
+            m = m / batch
+            cos = float((w * m).sum() / (w.norm() * m.norm()).clamp_min(1e-30))
+            rows[k].append((l2err(w, m), cos, n))
+        rows[k].sort(reverse=True)
+    print("config #3 batch 32 vs mean of per-sample gradients: worst dis", rows[0][:2], "gen", rows[1][:3],
+          "median gen", rows[1][len(rows[1]) // 2][:2])
+    assert len(rows[1]) >= 80
+    assert rows[0][0][0] <= 1e-2, rows[0][:3]
+    assert rows[1][0][0] <= 0.6 and min(r[1] for r in rows[1]) >= 0.8, rows[1][:4]

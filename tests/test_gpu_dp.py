@@ -34,9 +34,13 @@ def _step(trainer, hp, batch, record=False):
             ops.MASK_SINK = ops.L1_SINK = None
 
     run(lambda: trainer.dis_update(x_a, x_b, hp))
+    # no read of the discriminator buffers here: in data-parallel mode their exchange and optimizer step are still in flight on
+    # the communication stream (trainer._defer_dis_step) while gen_update's generator forward runs -- gen_update freezes the
+    # discriminators, so their gradient and weights are read after it
+    run(lambda: trainer.gen_update(x_a, x_b, hp, m_a, m_b))
+    torch.cuda.synchronize()
     g_dis = trainer.dis_opt.flat_g.detach().clone()
     dis_p = trainer.dis_opt.flat_p.detach().clone()
-    run(lambda: trainer.gen_update(x_a, x_b, hp, m_a, m_b))
     g_gen = trainer.gen_opt.flat_g.detach().clone()
     torch.cuda.synchronize()
     return g_dis.cpu(), g_gen.cpu(), dis_p.cpu(), kinks
@@ -51,24 +55,39 @@ def _worker(rank, world, tmpdir):
     dist.init_process_group("gloo", init_method="file://" + os.path.join(tmpdir, "rdzv"), rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     hp = bench.bench_hp(SIZE, B)
-    torch.manual_seed(1234)
-    tr = MUNIT_Trainer(hp)
-    tr.to(dev)
     batch = tuple(t.to(dev) for t in bench.make_batch(B, SIZE, rank))
     from munit_amd import trainer as T
-    assert T.OVERLAP_EXCHANGE                       # default: decoder / MLP half of the generator gradient goes out early
-    g_dis, g_gen, dis_p, kinks = _step(tr, hp, batch, record=True)
-    sd = {k: v.detach().cpu() for k, v in tr.gen.state_dict().items()}
-    # the same step with ONE all-reduce after backward: bitwise the same averaged gradient and weights (two ranks)
-    T.OVERLAP_EXCHANGE = False
-    torch.manual_seed(1234)
-    tr2 = MUNIT_Trainer(hp)
-    tr2.to(dev)
-    g_dis2, g_gen2, _, _ = _step(tr2, hp, batch)
-    T.OVERLAP_EXCHANGE = True
-    assert torch.equal(g_gen, g_gen2) and torch.equal(g_dis, g_dis2)
-    for (k, a), b in zip(sd.items(), tr2.gen.state_dict().values()):
-        assert torch.equal(a, b.detach().cpu()), k
+    assert T.OVERLAP_EXCHANGE                       # default: the generator gradient goes out in stages inside backward, the
+    # discriminator's exchange + optimizer step run on the communication stream beside the next generator forward
+    for guided in (1, 0):                           # guided 0: the sampled styles' MLP passes are tied into stage 1 by a gradient
+        hp_g = dict(hp, guided=guided)
+        torch.manual_seed(1234)
+        tr = MUNIT_Trainer(hp_g)
+        tr.to(dev)
+        out = _step(tr, hp_g, batch, record=(guided == 1))
+        stages = tr.last_exchange.stages
+        assert len(stages) == 2 and all(st["fired"] for st in stages), stages
+        assert stages[0]["ranges"] == [tuple(r) for r in tr._early_ranges] and stages[1]["ranges"] == [tuple(r) for r in tr._trunk_ranges]
+        assert tr._dis_pending is not None           # the discriminator step was deferred (and awaited by gen_update's D forward)
+        sd_g = {k: v.detach().cpu() for k, v in tr.gen.state_dict().items()}
+        sd_d = {k: v.detach().cpu() for k, v in tr.dis_a.state_dict().items()}
+        # the same step with ONE all-reduce after backward and the discriminator step in line: bitwise the same averaged
+        # gradients and weights (two ranks)
+        T.OVERLAP_EXCHANGE = False
+        torch.manual_seed(1234)
+        tr2 = MUNIT_Trainer(hp_g)
+        tr2.to(dev)
+        out2 = _step(tr2, hp_g, batch)
+        T.OVERLAP_EXCHANGE = True
+        assert tr2._dis_pending is None
+        assert torch.equal(out[1], out2[1]) and torch.equal(out[0], out2[0]) and torch.equal(out[2], out2[2]), guided
+        for (k, a), b in zip(sd_g.items(), tr2.gen.state_dict().values()):
+            assert torch.equal(a, b.detach().cpu()), (guided, k)
+        for (k, a), b in zip(sd_d.items(), tr2.dis_a.state_dict().values()):
+            assert torch.equal(a, b.detach().cpu()), (guided, k)
+        if guided == 1:
+            g_dis, g_gen, dis_p, kinks = out
+            sd = sd_g
     torch.save({"g_dis": g_dis, "g_gen": g_gen, "gen": sd, "dis_p": dis_p, "kinks": kinks},
                os.path.join(tmpdir, "rank%d.pt" % rank))
     dist.barrier()
@@ -246,6 +265,9 @@ torch.cuda.synchronize()
 assert torch.equal(g, ref)                        # SUM over one rank
 assert lib.munit_comm_allreduce(comm, None, 0, ctypes.c_void_p(st)) == 0
 assert lib.munit_comm_init(ctypes.byref(comm), 2, 1, uid) != 0 and b"bad arguments" in lib.munit_last_error()
+assert lib.munit_shutdown() != 0 and b"still alive" in lib.munit_last_error()     # refused while the communicator lives
+assert lib.munit_comm_allreduce(comm, ctypes.c_void_p(g.data_ptr()), g.numel(), ctypes.c_void_p(st)) == 0   # ... and nothing was unloaded
+torch.cuda.synchronize()
 assert lib.munit_comm_destroy(comm) == 0
 assert lib.munit_shutdown() == 0
 print("comm ok")

@@ -171,7 +171,7 @@ def test_linear():
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (3, 256, 8, 8), (1, 128, 31, 17), (2, 48, 5, 7)])
-@pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res"])
+@pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res", "in_lrelu", "adain_tanh", "adain_lrelu"])
 def test_instance_norm(shape, mode):
     from munit_amd import ops
     B, C, H, W = shape
@@ -186,7 +186,11 @@ def test_instance_norm(shape, mode):
         yr = O.adain(xr, pr[:, w_off:w_off + C], pr[:, b_off:b_off + C])
     else:
         yr = O.instance_norm(xr)
-    if mode.endswith("relu"):
+    if mode.endswith("lrelu"):        # networks.py:672 nn.LeakyReLU(0.2) behind a norm (networks.py:695-701): fused into the norm kernels
+        yr = torch.nn.functional.leaky_relu(yr, 0.2)
+    elif mode.endswith("tanh"):
+        yr = torch.tanh(yr)
+    elif mode.endswith("relu"):
         yr = torch.clamp_min(yr, 0)
     if mode.endswith("res"):
         yr = yr + rr
@@ -196,7 +200,7 @@ def test_instance_norm(shape, mode):
     xd = x.float().to(dev()).requires_grad_(True)
     pd = params.float().to(dev()).requires_grad_(True)
     rd = res.float().to(dev()).requires_grad_(True)
-    relu = mode.endswith("relu")
+    relu = "lrelu" if mode.endswith("lrelu") else "tanh" if mode.endswith("tanh") else mode.endswith("relu")
     residual = rd if mode.endswith("res") else None
     if mode.startswith("adain"):
         y = ops.adain(xd, pd, w_off, b_off, relu, residual)
@@ -212,7 +216,7 @@ def test_instance_norm(shape, mode):
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 16, 16), (1, 64, 33, 9), (3, 64, 8, 8)])
-@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("relu", [False, True, "lrelu", "tanh"])
 def test_layer_norm(shape, relu):
     from munit_amd import ops
     B, C, H, W = shape
@@ -221,7 +225,11 @@ def test_layer_norm(shape, relu):
     bt = rnd((C,), 3, 0.3)
     xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, bt))
     yr = O.munit_layer_norm(xr, gr, br)
-    if relu:
+    if relu == "lrelu":
+        yr = torch.nn.functional.leaky_relu(yr, 0.2)
+    elif relu == "tanh":
+        yr = torch.tanh(yr)
+    elif relu:
         yr = torch.clamp_min(yr, 0)
     dy = rnd(shape, 4)
     yr.backward(dy)

@@ -60,7 +60,7 @@ def make_batch(batch, size, rank=0):
     return x_a, x_b, m_a, m_b
 
 
-PMC_SUMMARY = "profiles/r03_pmc_hbm_mfma.txt"
+PMC_SUMMARY = "profiles/r04_pmc_hbm_mfma.txt"
 
 
 def lib_fingerprint():

@@ -137,9 +137,7 @@ enum { MUNIT_PASS_FWD = 0, MUNIT_PASS_DGRAD = 1, MUNIT_PASS_WGRAD = 2 };
 enum { MUNIT_PREP_NONE = 0, MUNIT_PREP_DGRAD = 1, MUNIT_PREP_SUBPIXEL = 2, MUNIT_PREP_CAST = 3,
        MUNIT_PREP_WINOGRAD = 4, MUNIT_PREP_WINOGRAD_DGRAD = 5, MUNIT_PREP_SUBPIXEL_WINOGRAD = 6,
        MUNIT_PREP_WINOGRAD_S2 = 7, MUNIT_PREP_WINOGRAD_S2_DGRAD = 8,
-       MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD = 9 /* [the _DGRAD image][Winograd image of the four rotated phase filters] */,
-       MUNIT_PREP_WINOGRAD43 = 10 /* the 36-frequency G g G^T image of Winograd F(4x4, 3x3) (forward of the 3x3 layers) */,
-       MUNIT_PREP_SUBPIXEL_WINOGRAD43 = 11 /* the same for the four merged 3x3 phase filters of a sub-pixel up-sampling layer */ };
+       MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD = 9 /* [the _DGRAD image][Winograd image of the four rotated phase filters] */ };
 typedef struct {
   const float* w; /* [Cout][KH][KW][Cin] */
   float* wp;      /* image, munit_conv2d_prepared_weight_bytes() bytes (bf16 elements when bf16 != 0) */

@@ -876,8 +876,6 @@ __host__ __device__ inline long long prep_elems(const PrepItem& it) {
   const long long cc = (long long)it.Cout * it.Cin;
   if (it.kind == MUNIT_PREP_SUBPIXEL) return it.bf16 ? (4 * 9 + 25) * cc : 4 * 9 * cc;
   if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD) return wino_image_elems(it.Cin, it.Cout);
-  if (it.kind == MUNIT_PREP_WINOGRAD43) return wino43_image_elems(it.Cin, it.Cout);
-  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) return 4 * wino43_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return cc * it.KH * it.KW + 4 * wino_image_elems(it.Cin, it.Cout);
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD)
     return 4 * wino_image_elems(it.Cin, it.Cout);
@@ -891,8 +889,6 @@ __host__ __device__ inline long long prep_trips(const PrepItem& it) {
   const bool wino = it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD ||
                     it.kind == MUNIT_PREP_WINOGRAD_S2 || it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD) return (long long)it.Cout * it.Cin * (it.KH * it.KW + 4);
-  if (it.kind == MUNIT_PREP_WINOGRAD43) return (long long)it.Cout * it.Cin;   // one trip = one channel pair, 36 elements
-  if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) return 4ll * it.Cout * it.Cin;
   return wino ? prep_elems(it) / 16 : prep_elems(it);
 }
 template <bool DEV>
@@ -903,8 +899,6 @@ __global__ void prep_weights_kernel(const PrepItem* __restrict__ items, PrepItem
     if (it.kind == MUNIT_PREP_SUBPIXEL) prep_subpixel_elem(it, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD || it.kind == MUNIT_PREP_WINOGRAD_DGRAD)
       wino_weight_item(it.w, it.wp, it.Cout, it.Cin, it.kind == MUNIT_PREP_WINOGRAD_DGRAD, i);
-    else if (it.kind == MUNIT_PREP_WINOGRAD43) wino43_weight_item(it.w, it.wp, it.Cout, it.Cin, false, i);
-    else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) wino43_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) wino_subpixel_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2) wino_s2_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
     else if (it.kind == MUNIT_PREP_WINOGRAD_S2_DGRAD) wino_s2_dgrad_weight_item(it.w, it.wp, it.Cout, it.Cin, i);
@@ -1213,12 +1207,17 @@ bool wino_geometry_ok(const munit_conv_desc* d) {
          d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->upsample == 0 && d->act != MUNIT_ACT_TANH;
 }
 bool wino_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
-// the same layers through F(4x4, 3x3) (conv_wino43.hip) where the extent is a multiple of 4 and Cin of 32: 36 instead of 64
-// multiply-accumulates per 16 outputs and channel pair
-bool wino43_fwd_ok(const munit_conv_desc* d) { return wino_geometry_ok(d) && munit_wino43_ok(d->B, d->H, d->W, d->Cin, d->Cout); }
 // MUNIT_WINO_S2_MIN_BLOCKS: developer override of the threshold (tests use 1 to push small shapes through the kernel)
 long long wino_s2_min_blocks() {
   static const long long v = getenv("MUNIT_WINO_S2_MIN_BLOCKS") ? atoll(getenv("MUNIT_WINO_S2_MIN_BLOCKS")) : 192;
+  return v;
+}
+// Backward-data takes the Winograd form further down: its alternative is four phase launches of the implicit GEMM plus the
+// fold kernel.  Measured per launch (tools/time_layers.py s2small, round 4): 144 blocks (discriminator 256->512 at 32x32, fake +
+// real) 282 -> 166 us, 128 blocks (128->256 at 64x64) 153 -> 93, 124 blocks 77 -> 58; 80 blocks 138 -> 160 and 72 blocks
+// 85 -> 90 the other way.
+long long wino_s2_dgrad_min_blocks() {
+  static const long long v = getenv("MUNIT_WINO_S2_MIN_BLOCKS") ? atoll(getenv("MUNIT_WINO_S2_MIN_BLOCKS")) : 100;
   return v;
 }
 // 4x4 / stride 2 / pad 1 fp32 layers (encoder down-sampling, discriminators): F(3x3, 2x2) over the four input phases
@@ -1239,17 +1238,12 @@ bool wino_s2_dgrad_ok(const munit_conv_desc* d) {
   const int Hd = d->H / 2, Wd = d->W / 2;
   if (d->pad_mode == MUNIT_PAD_REFLECT && (Hd % 3 == 0 || Wd % 3 == 0)) return false;   // fold pairs must share a 3x3 tile
   if ((long long)d->B * d->H * d->W * std::max(d->Cin, d->Cout) >= (1ll << 29)) return false;
-  return (long long)cdiv((long long)d->B * cdiv(Hd + 1, 3) * cdiv(Wd + 1, 3), 64) * (d->Cin / 64) * 4 >= wino_s2_min_blocks();
+  return (long long)cdiv((long long)d->B * cdiv(Hd + 1, 3) * cdiv(Wd + 1, 3), 64) * (d->Cin / 64) * 4 >= wino_s2_dgrad_min_blocks();
 }
 // the four 3x3 phase convs of a sub-pixel up-sampling layer (over the SOURCE image) through the Winograd kernel
 bool subpixel_wino_ok(const munit_conv_desc* d) {
   return subpixel_ok(d) && d->compute == MUNIT_COMPUTE_F32 && d->in_dtype == MUNIT_DTYPE_F32 && d->out_dtype == MUNIT_DTYPE_F32 &&
          d->act != MUNIT_ACT_TANH && munit_wino_ok(d->B, d->H, d->W, d->Cin, d->Cout);
-}
-
-// ... and through F(4x4, 3x3) where the source extent is a multiple of 4
-bool subpixel_wino43_ok(const munit_conv_desc* d) {
-  return subpixel_wino_ok(d) && munit_wino43_ok(d->B, d->H, d->W, d->Cin, d->Cout);
 }
 
 // forward: which re-laid-out weight image the pass multiplies by (MUNIT_PREP_NONE: w as it is) and its size
@@ -1258,8 +1252,7 @@ munit_prep_item fwd_prep_item(const munit_conv_desc* d, const float* w, float* w
   const bool small = munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD");
   if (small) return it;
   it.bf16 = d->in_dtype == MUNIT_DTYPE_BF16;
-  if (subpixel_ok(d)) it.kind = subpixel_wino43_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD43 : subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
-  else if (wino43_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD43;
+  if (subpixel_ok(d)) it.kind = subpixel_wino_ok(d) ? MUNIT_PREP_SUBPIXEL_WINOGRAD : MUNIT_PREP_SUBPIXEL;
   else if (wino_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD;
   else if (wino_s2_fwd_ok(d)) it.kind = MUNIT_PREP_WINOGRAD_S2;
   else if (it.bf16) it.kind = MUNIT_PREP_CAST;
@@ -1276,7 +1269,7 @@ extern "C" size_t munit_conv2d_fwd_workspace_bytes(const munit_conv_desc* d) {
   // [weight image of the pass, when the caller keeps none][split-K slabs]
   const size_t img = prep_bytes(fwd_prep_item(d, nullptr, nullptr));
   if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return munit_small_fwd_workspace(d);
-  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino43_fwd_ok(d) || wino_fwd_ok(d) || wino_s2_fwd_ok(d)) return img;
+  if (munit_small_fwd_supported(d) || d->in_dtype == MUNIT_DTYPE_BF16 || wino_fwd_ok(d) || wino_s2_fwd_ok(d)) return img;
   if (cin4_fwd_ok(d)) {   // [4-channel image][padded weights]
     const Cin4Plan c = plan_cin4((long long)d->B * d->H * d->W, d->Cout, d->KH * d->KW);
     return c.x4_bytes + c.w4_bytes;
@@ -1339,17 +1332,6 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.act = d->act; q.slope = d->slope;
     return munit_wino_launch(q, st);
   }
-  if (it.kind == MUNIT_PREP_WINOGRAD43) {
-    WinoParams q{};
-    q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
-    q.y_sw = d->Cout; q.y_sh = (long long)d->W * d->Cout; q.y_sb = (long long)d->H * d->W * d->Cout;
-    q.B = d->B; q.H = d->H; q.W = d->W; q.K = d->Cin; q.N = d->Cout; q.xc = d->Cin; q.cpp = d->Cin / 8;
-    q.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
-    q.mode = d->pad_mode == MUNIT_PAD_REFLECT ? 0 : 1;
-    q.th = d->H / 4; q.tw = d->W / 4; q.bth = cdiv(q.th, 4); q.btw = cdiv(q.tw, 4); q.NB = d->Cout / 64;
-    q.act = d->act; q.slope = d->slope;
-    return munit_wino43_launch(q, st);
-  }
   if (it.kind == MUNIT_PREP_WINOGRAD) {
     WinoParams q{};
     q.x = reinterpret_cast<const float*>(x); q.u = wimg; q.bias = bias; q.y = reinterpret_cast<float*>(y);
@@ -1391,7 +1373,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     p.Ktot = c.kpad; p.w_row = c.kpad; p.cin4 = 1;
     return launch_igemm<0>(p, 1, st);
   }
-  if (it.kind == MUNIT_PREP_SUBPIXEL || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) {
+  if (it.kind == MUNIT_PREP_SUBPIXEL || it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
     // (1) four phase convs (3x3 over the source, merged weights) write every output pixel; the 2-pixel
     // frame, where reflect padding breaks the merge, is then (2) recomputed by the generic 25-tap gather.
     IgemmParams q = p;
@@ -1407,18 +1389,7 @@ extern "C" int munit_conv2d_fwd_prepared(const munit_conv_desc* d, const void* x
     q.w_phase = (long long)d->Cout * q.Ktot;
     q.y_phase_row = (long long)Wo * d->Cout;
     q.y_phase_col = d->Cout;
-    if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43) {
-      WinoParams wq{};
-      wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
-      wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
-      wq.u_phase = wino43_image_elems(d->Cin, d->Cout); wq.y_prow = q.y_phase_row; wq.y_pcol = q.y_phase_col; wq.phases = 4;
-      wq.B = d->B; wq.H = d->H; wq.W = d->W; wq.K = d->Cin; wq.N = d->Cout; wq.xc = d->Cin; wq.cpp = d->Cin / 8;
-      wq.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * 4);
-      wq.mode = 1;
-      wq.th = d->H / 4; wq.tw = d->W / 4; wq.bth = cdiv(wq.th, 4); wq.btw = cdiv(wq.tw, 4); wq.NB = d->Cout / 64;
-      wq.act = d->act; wq.slope = d->slope;
-      rc = munit_wino43_launch(wq, st);
-    } else if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
+    if (it.kind == MUNIT_PREP_SUBPIXEL_WINOGRAD) {
       WinoParams wq{};
       wq.x = reinterpret_cast<const float*>(x); wq.u = wimg; wq.bias = bias; wq.y = reinterpret_cast<float*>(y);
       wq.y_sw = q.y_sw; wq.y_sh = q.y_sh; wq.y_sb = p.y_sb;
@@ -1856,9 +1827,8 @@ extern "C" size_t munit_conv2d_prepared_weight_bytes(const munit_conv_desc* d, i
 
 extern "C" int munit_conv2d_prepare_weights(const munit_prep_item* item, munit_stream_t stream) {
   MUNIT_CHECK_ARG(item && item->w && item->wp, "conv2d_prepare_weights: null pointer");
-  const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD || item->kind == MUNIT_PREP_WINOGRAD43;
-  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD ||
-                   item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD43;
+  const bool wino = item->kind == MUNIT_PREP_WINOGRAD || item->kind == MUNIT_PREP_WINOGRAD_DGRAD;
+  const bool spw = item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD || item->kind == MUNIT_PREP_SUBPIXEL_WINOGRAD_DGRAD;
   const bool ws2 = item->kind == MUNIT_PREP_WINOGRAD_S2 || item->kind == MUNIT_PREP_WINOGRAD_S2_DGRAD;
   MUNIT_CHECK_ARG(!ws2 || (item->KH == 4 && item->KW == 4 && !item->bf16 &&
                            (item->kind == MUNIT_PREP_WINOGRAD_S2 ? item->Cin % 8 == 0 && item->Cout % 64 == 0
@@ -1897,10 +1867,8 @@ const char* munit_igemm_kernel_name(const munit_conv_desc* d, int pass) {
   const bool refl = d->pad_mode == MUNIT_PAD_REFLECT;
   if (pass == MUNIT_PASS_FWD) {
     if (munit_small_fwd_supported(d) && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_SMALL_FWD")) return "conv_head_pk_kernel";
-    if (subpixel_wino43_ok(d)) return "conv_wino43_kernel<1> x4 sub-pixel phases + conv_igemm_kernel frame";
     if (subpixel_wino_ok(d)) return "conv_wino_kernel<1, 0> x4 sub-pixel phases + conv_igemm_kernel frame";
     if (subpixel_ok(d)) return "conv_igemm_kernel x4 sub-pixel phases + frame";
-    if (wino43_fwd_ok(d)) return refl ? "conv_wino43_kernel<0>" : "conv_wino43_kernel<1>";
     if (wino_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 0>" : "conv_wino_kernel<1, 0>";
     if (wino_s2_fwd_ok(d)) return refl ? "conv_wino_kernel<0, 1>" : "conv_wino_kernel<1, 1>";
     if (cin4_fwd_ok(d)) return "conv_igemm_kernel<.., 5> (3 input channels as 4-channel taps)";
@@ -1925,10 +1893,8 @@ double munit_igemm_executed_flops(const munit_conv_desc* d, int pass) {
   if (munit_conv2d_out_hw(d, &Ho, &Wo)) return 0.0;
   const double cc = 2.0 * d->Cin * d->Cout;
   if (pass == MUNIT_PASS_FWD) {
-    if (subpixel_wino43_ok(d)) return cc * d->B * ((double)(d->H / 4) * (d->W / 4) * 4 * 36 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
     if (subpixel_wino_ok(d)) return cc * d->B * ((double)(d->H / 2) * (d->W / 2) * 4 * 16 + (2.0 * Wo + 2.0 * (Ho - 2)) * 25);
     if (subpixel_ok(d)) return cc * d->B * ((double)d->H * d->W * 4 * 9 + (4.0 * Wo + 4.0 * (Ho - 4)) * 25);
-    if (wino43_fwd_ok(d)) return cc * d->B * (d->H / 4) * (d->W / 4) * 36;   // F(4x4, 3x3): 36 products per 4x4 tile instead of 144
     if (wino_fwd_ok(d)) return cc * d->B * (d->H / 2) * (d->W / 2) * 16;   // 16 products per 2x2 tile instead of 36
     if (wino_s2_fwd_ok(d)) return 4 * cc * d->B * cdiv(Ho, 3) * cdiv(Wo, 3) * 16;   // per 3x3 tile and input phase
     if (cin4_fwd_ok(d) && !munit_small_fwd_supported(d))   // zero 4th input channel, K padded to the 32-wide tile

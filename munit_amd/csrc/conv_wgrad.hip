@@ -1217,7 +1217,10 @@ extern "C" const char* munit_conv2d_kernel_name(const munit_conv_desc* d, int pa
   // (the second template argument mirrors the FAST decision of munit_wino_wgrad_launch)
   if (wino_s2_wgrad_layer(d)) {
     const bool fast = s2_tiles(d) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT && d->H % 6 == 0 && d->W % 6 == 0 && Ho % 3 == 0 && Wo % 3 == 0;
-    return fast ? "conv_wino_wgrad_kernel<true, true, false> + wino_wgrad_reduce_kernel" : "conv_wino_wgrad_kernel<true, false, false> + wino_wgrad_reduce_kernel";
+    const bool xclamp = !fast && s2_tiles(d) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT;   // mirrors munit_wino_wgrad_launch
+    return fast ? "conv_wino_wgrad_kernel<true, true, false> + wino_wgrad_reduce_kernel"
+                : xclamp ? "conv_wino_wgrad_kernel<true, false, true> + wino_wgrad_reduce_kernel"
+                         : "conv_wino_wgrad_kernel<true, false, false> + wino_wgrad_reduce_kernel";
   }
   if (wino_wgrad_layer(d)) {
     const bool fast = ((long long)d->B * (d->H / 2) * (d->W / 2)) % 8 == 0 && d->pad_mode == MUNIT_PAD_REFLECT;

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int t = cur_t + e;
-      if (FAST || t < p.tiles) {
+      if (FAST || (S2 && RING) || t < p.tiles) {
         int tx = cur_tx + e, ty = cur_ty, b = cur_b;
         if (tx >= p.tw) { tx -= p.tw; if (++ty >= p.th) { ty = 0; ++b; } }
         if (xside) {
@@ -592,7 +592,10 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
             int ih, iw;
             if constexpr (S2) {   // row q of input phase r = image row 2q + r - 1; the padded rows -1 and H reflect (or read 0)
               ih = 2 * (3 * ty + i) + (phase >> 1) - 1; iw = 2 * (3 * tx + i) + (phase & 1) - 1;
-              if (p.reflect) {
+              if constexpr (RING) {   // S2 + RING = reflect-padded layer whose 3x3 tiles overhang the output (XCLAMP, see the launch)
+                ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : min(ih, p.H - 1));
+                iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : min(iw, p.W - 1));
+              } else if (p.reflect) {
                 ih = ih == -1 ? 1 : (ih == p.H ? p.H - 2 : ih);
                 iw = iw == -1 ? 1 : (iw == p.W ? p.W - 2 : iw);
               }
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
                 iw = iw < 0 ? -iw : (iw >= p.W ? 2 * p.W - 2 - iw : iw);
               }
             }
-            if constexpr (FAST) {
+            if constexpr (FAST || (S2 && RING)) {
               ro[i] = (b * p.H + ih) * p.W; co[i] = iw;
             } else {
               ro[i] = (unsigned)ih < (unsigned)p.H ? (b * p.H + ih) * p.W : -1;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(WinoWgradParams p)
               // the 4x4 / stride 2 layers mark an invalid position by a lane offset beyond the buffer (the load returns 0) instead
               // of branching around the load: 254 -> 245 us; for the sub-pixel layers the branch form measured 1 % faster
               if constexpr (S2) {
-                const bool ok = FAST || (ro[i] >= 0 && co[j] >= 0);
+                const bool ok = FAST || RING || (ro[i] >= 0 && co[j] >= 0);
                 d[i * 4 + j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     xres, ok ? xlane : 0x80000000u, ok ? (ro[i] + co[j]) * p.Cin * 4 : 0, 0));
               } else {
@@ -926,7 +929,14 @@ int munit_wino_wgrad_launch(WinoWgradParams p, float* dw, long long dw_phase, fl
   else fast = fast && (p.xo == -1 ? (p.reflect && p.H >= 2 && p.W >= 2 && 2 * p.th <= p.H && 2 * p.tw <= p.W)
                                   : (p.xo >= 0 && 2 * (p.th - 1) + p.xo + 3 < p.H && 2 * (p.tw - 1) + p.xo + 3 < p.W));
   if (p.s2) {
+    // XCLAMP (<true, false, true>): a reflect-padded layer whose 3x3 tiles overhang the output (Ho % 3 != 0 -- every power-of-two
+    // extent) with every tile of every chunk present.  The overhanging dy positions are read as 0 (guarded, 9 loads per tile), so
+    // the input positions that meet ONLY them may hold any finite value: the x side -- 32 loads per wave and chunk -- clamps them
+    // into the image and drops its per-load validity selects.  Exact in the sense of the transform (linear; the products with a
+    // zero gradient cancel), and the op tests hold it to the same bound as the guarded form.
+    const bool xclamp = !fast && p.reflect == 1 && p.tiles % 8 == 0 && p.H >= 2 && p.W >= 2 && !MUNIT_ENV_FLAG("MUNIT_DEBUG_NO_WINO_WGRAD_FAST");
     if (fast) hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, true>), grid, dim3(512), 0, st, p);
+    else if (xclamp) hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, false, true>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<true, false>), grid, dim3(512), 0, st, p);
   } else if (p.ring_mask) {
     MUNIT_CHECK_ARG(p.reflect == 2 && p.xo == -1 && p.phases == 4, "conv_wino_wgrad: ring_mask goes with the replicated edge and 4 phases");

@@ -163,95 +163,6 @@ __device__ inline void wino_subpixel_weight_item(const float* __restrict__ w, fl
   wino_store_item(img + ph * wino_image_elems(Cin, Cout), j - ph * per, g);
 }
 
-// ---- F(4x4, 3x3) (conv_wino43.hip): 36 frequencies f = 6*fi + fj, U = G g G^T with
-// G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]  (interpolation points 0, +-1, +-2, inf).
-// Image: [c8 = K/8][nb = N/64][f = 36][512] floats, the 512 in the same MFMA B-fragment order as the F(2x2,3x3) image
-// (wino_item_index).
-__host__ __device__ inline long long wino43_image_elems(int K, int N) { return 36ll * K * N; }
-__device__ inline void wino43_g1d(float a, float b, float c, float (&o)[6]) {
-  const float s = a + c;
-  o[0] = 0.25f * a;
-  o[1] = (-1.f / 6.f) * (s + b);
-  o[2] = (-1.f / 6.f) * (s - b);
-  const float q = (1.f / 24.f) * a + (1.f / 6.f) * c, h = (1.f / 12.f) * b;
-  o[3] = q + h;
-  o[4] = q - h;
-  o[5] = c;
-}
-// item j = one (contraction channel k, produced channel no) pair, all 36 frequencies
-__device__ inline void wino43_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, bool dgrad, long long j) {
-  int k, no;
-  wino_item_index(j, dgrad ? Cin : Cout, k, no);
-  float t[6][3];   // G g
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    float g0, g1, g2;
-    if (dgrad) {
-      g0 = w[(((long long)k * 3 + 2) * 3 + (2 - s)) * Cin + no];
-      g1 = w[(((long long)k * 3 + 1) * 3 + (2 - s)) * Cin + no];
-      g2 = w[(((long long)k * 3 + 0) * 3 + (2 - s)) * Cin + no];
-    } else {
-      g0 = w[(((long long)no * 3 + 0) * 3 + s) * Cin + k];
-      g1 = w[(((long long)no * 3 + 1) * 3 + s) * Cin + k];
-      g2 = w[(((long long)no * 3 + 2) * 3 + s) * Cin + k];
-    }
-    float col[6];
-    wino43_g1d(g0, g1, g2, col);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) t[i][s] = col[i];
-  }
-  float* o = img + (j >> 9) * (36 * 512) + (j & 511);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float row[6];
-    wino43_g1d(t[i][0], t[i][1], t[i][2], row);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) o[(i * 6 + q) * 512] = row[q];
-  }
-}
-// 36 frequencies of the 3x3 filter g in the image order
-__device__ inline void wino43_store_item(float* __restrict__ img, long long j, const float (&g)[3][3]) {
-  float t[6][3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    float col[6];
-    wino43_g1d(g[0][s], g[1][s], g[2][s], col);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) t[i][s] = col[i];
-  }
-  float* o = img + (j >> 9) * (36 * 512) + (j & 511);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float row[6];
-    wino43_g1d(t[i][0], t[i][1], t[i][2], row);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) o[(i * 6 + q) * 512] = row[q];
-  }
-}
-// sub-pixel up-sampling layer (see wino_subpixel_weight_item): [phase 4][the 36-frequency image of that phase's merged 3x3 filter]
-__device__ inline void wino43_subpixel_weight_item(const float* __restrict__ w, float* __restrict__ img, int Cout, int Cin, long long j) {
-  const long long per = (long long)Cin * Cout;
-  const int ph = (int)(j / per), a = ph >> 1, b = ph & 1;
-  int k, no;
-  wino_item_index(j - ph * per, Cout, k, no);
-  float g[3][3];
-#pragma unroll
-  for (int dh = 0; dh < 3; ++dh)
-#pragma unroll
-    for (int dw = 0; dw < 3; ++dw) {
-      const int h0 = a == 0 ? (dh == 0 ? 0 : dh == 1 ? 2 : 4) : (dh == 0 ? 0 : dh == 1 ? 1 : 3);
-      const int hn = a == 0 ? (dh == 2 ? 1 : 2) : (dh == 0 ? 1 : 2);
-      const int w0 = b == 0 ? (dw == 0 ? 0 : dw == 1 ? 2 : 4) : (dw == 0 ? 0 : dw == 1 ? 1 : 3);
-      const int wn = b == 0 ? (dw == 2 ? 1 : 2) : (dw == 0 ? 1 : 2);
-      float s = 0.f;
-      for (int kh = h0; kh < h0 + hn; ++kh)
-        for (int kw = w0; kw < w0 + wn; ++kw) s += w[(((long long)no * 5 + kh) * 5 + kw) * Cin + k];
-      g[dh][dw] = s;
-    }
-  wino43_store_item(img + ph * wino43_image_elems(Cin, Cout), j - ph * per, g);
-}
-bool munit_wino43_ok(int B, int H, int W, int K, int N);
-
 struct WinoParams {
   const float* x;      // NHWC input [B][H][W][K]
   const float* u;      // transformed weights (see above)
@@ -280,9 +191,6 @@ struct WinoParams {
 // shapes the kernel takes (conv_wino.hip)
 bool munit_wino_ok(int B, int H, int W, int K, int N);
 int munit_wino_launch(const WinoParams& p, hipStream_t st);
-// F(4x4, 3x3) forward of a 3x3 / stride 1 / pad 1 layer (conv_wino43.hip): p.th, p.tw = 4x4-pixel tiles per axis, p.bth, p.btw =
-// blocks of 4x4 tiles, p.u = the 36-frequency image; mode 0 reflect / 1 zero padding; phases as munit_wino_launch
-int munit_wino43_launch(const WinoParams& p, hipStream_t st);
 
 // ---- backward-weight: dg = G^T [ sum_tiles (A dY A^T) . (B^T d B) ] G  (conv_wino.hip) ----
 struct WinoWgradParams {

@@ -424,6 +424,7 @@ class MUNIT_Trainer(_ApplyRefreshesImages, nn.Module):
         self.reuse_dis_forward = bool(hyperparameters.get("reuse_dis_forward", 0))
         self._fwd_cache = None
         self.fwd_reused = False     # whether the last gen_update continued from dis_update's forward
+        self.last_exchange = None   # the GradExchange of the last data-parallel gen_update (introspection)
 
         optimizer = FusedExtraAdam if "extra" in hyperparameters["optimizer"] else FusedAdam  # trainer.py:41-45
         self.domain_classif_ab = hyperparameters.get("domain_adv_w", 0) > 0

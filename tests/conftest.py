@@ -30,6 +30,8 @@ def usable_cpus():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "frozen_mode: GPU tests of the frozen arithmetic modes (f32x3, operand-only bf16); part of "
+                            "-m gpu, can be left out with -m 'gpu and not frozen_mode'")
     import torch
     # the oracle (CPU, fp64) is where the suite's time goes; beyond ~32 threads its small fp64 convolutions gain nothing
     torch.set_num_threads(max(1, min(usable_cpus(), torch.get_num_threads(), 32)))

@@ -1,6 +1,7 @@
 """CPU (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
 mirror of the reference interface (module tree, state_dict keys, init RNG stream, config
 defaults, LR schedule, optimizer state format) and the data-parallel exchange over gloo."""
+import ctypes
 import os
 import re
 import subprocess
@@ -547,3 +548,37 @@ def test_bench_sizes_host_threads_from_the_granted_cpus(monkeypatch):
     assert bench.rank_threads(2) == max(1, bench.usable_cpus() // 2)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("os.cpu_count()") == 2                     # the docstring and the no-sched_getaffinity fallback of usable_cpus
+
+
+def test_kernel_names_reported_by_the_library_exist_in_the_committed_trace():
+    """munit_conv2d_kernel_name feeds bench.py's roofline table and its lookup in the PMC summary: a name of a kernel that does
+    not run (round 3: the image head's backward-weight was reported as conv_lanes_wgrad_kernel while conv_lanes_wgrad_pk_kernel
+    ran) silently drops the traffic figure.  For the dominant layers of BASELINE configs[1] every reported kernel must appear in
+    the newest committed rocprofv3 by-grid trace of that workload -- Winograd instantiations with their exact template
+    arguments, the others by kernel name."""
+    import glob
+    import re
+    from munit_amd import _lib, ops
+    traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernel_trace_by_grid_single_stream_bench_256_b8.txt")))
+    assert traces, "no committed kernel trace"
+    text = open(traces[-1]).read()
+    lib = _lib.load()
+    lib.munit_conv2d_kernel_name.restype = ctypes.c_char_p
+    layers = [(8, 64, 64, 256, 256, 3, 1, 1, False), (8, 256, 256, 64, 128, 4, 2, 1, False), (8, 128, 128, 128, 256, 4, 2, 1, False),
+              (8, 64, 64, 256, 128, 5, 1, 2, True), (8, 128, 128, 128, 64, 5, 1, 2, True), (8, 256, 256, 64, 3, 7, 1, 3, False),
+              (8, 256, 256, 3, 64, 7, 1, 3, False), (16, 128, 128, 64, 128, 4, 2, 1, False)]
+    seen = set()
+    for (b, h, w, ci, co, k, s, p, up) in layers:
+        pl = ops._plan(b, h, w, ci, co, k, k, s, p, "reflect", up, "none", 0.2, 0, 0)
+        for which in (0, 1, 2):
+            name = lib.munit_conv2d_kernel_name(pl.ref, which).decode()
+            for part in re.split(r" \+ | x4 ", name):
+                part = part.split(" (")[0].strip()
+                m = re.match(r"([a-z_0-9]+_kernel)(<[^>]*>)?", part)
+                if not m:
+                    continue
+                base, targs = m.group(1), m.group(2)
+                exact = base + targs if (targs and "." not in targs and base.startswith("conv_wino")) else base
+                seen.add(exact)
+                assert exact[:44] in text, (name, exact, os.path.basename(traces[-1]))
+    assert "conv_lanes_wgrad_pk_kernel" in seen and "conv_wino_kernel<0, 0>" in seen and len(seen) >= 10, seen

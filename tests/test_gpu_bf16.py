@@ -9,7 +9,9 @@ import torch
 from oracle import munit_oracle as O
 from tests.parity import nerr
 
-pytestmark = pytest.mark.gpu
+# frozen_mode: an arithmetic mode no BASELINE.json config asks for (f32x3; bf16 MFMA operands on fp32 storage -- superseded by the
+# bf16-storage mode `bf16s`).  Frozen since round 3: kept working, no further work; `-m "gpu and not frozen_mode"` leaves them out.
+pytestmark = [pytest.mark.gpu, pytest.mark.frozen_mode]
 
 BF16_VS_ORACLE = 2e-2     # stated tolerance of the bf16 configuration (forward)
 SHARP = 2e-5              # vs the fp64 result on bf16-rounded operands

@@ -59,31 +59,48 @@ def _worker(rank, world, tmpdir):
     from munit_amd import trainer as T
     assert T.OVERLAP_EXCHANGE                       # default: the generator gradient goes out in stages inside backward, the
     # discriminator's exchange + optimizer step run on the communication stream beside the next generator forward
+    # ONE trainer serves the four runs (guided 1 / 0 x staged / serial exchange): construction and the first-use build of the
+    # prepared weight images dominate this test's time.  Between runs the weights, the Adam moments and the step counters go
+    # back to the initial state, so every run is the FIRST update of the same trainer.
+    torch.manual_seed(1234)
+    tr = MUNIT_Trainer(dict(hp))
+    tr.to(dev)
+    init = [(o, o.flat_p.detach().clone()) for o in (tr.gen_opt, tr.dis_opt)]
+
+    def fresh(guided):
+        tr._settle_dis()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for o, p0 in init:
+                o.flat_p.copy_(p0)
+                o.flat_m.zero_()
+                o.flat_v.zero_()
+                o._step = 0
+                o.invalidate_prepared()
+        tr.guided = guided
+        tr.last_exchange = None
+        return dict(hp, guided=guided)
+
     for guided in (1, 0):                           # guided 0: the sampled styles' MLP passes are tied into stage 1 by a gradient
-        hp_g = dict(hp, guided=guided)
-        torch.manual_seed(1234)
-        tr = MUNIT_Trainer(hp_g)
-        tr.to(dev)
+        hp_g = fresh(guided)
         out = _step(tr, hp_g, batch, record=(guided == 1))
         stages = tr.last_exchange.stages
         assert len(stages) == 2 and all(st["fired"] for st in stages), stages
         assert stages[0]["ranges"] == [tuple(r) for r in tr._early_ranges] and stages[1]["ranges"] == [tuple(r) for r in tr._trunk_ranges]
         assert tr._dis_pending is not None           # the discriminator step was deferred (and awaited by gen_update's D forward)
-        sd_g = {k: v.detach().cpu() for k, v in tr.gen.state_dict().items()}
-        sd_d = {k: v.detach().cpu() for k, v in tr.dis_a.state_dict().items()}
+        sd_g = {k: v.detach().cpu().clone() for k, v in tr.gen.state_dict().items()}
+        sd_d = {k: v.detach().cpu().clone() for k, v in tr.dis_a.state_dict().items()}
         # the same step with ONE all-reduce after backward and the discriminator step in line: bitwise the same averaged
         # gradients and weights (two ranks)
+        hp_g = fresh(guided)
         T.OVERLAP_EXCHANGE = False
-        torch.manual_seed(1234)
-        tr2 = MUNIT_Trainer(hp_g)
-        tr2.to(dev)
-        out2 = _step(tr2, hp_g, batch)
+        out2 = _step(tr, hp_g, batch)
         T.OVERLAP_EXCHANGE = True
-        assert tr2._dis_pending is None
+        assert tr._dis_pending is None and tr.last_exchange is None
         assert torch.equal(out[1], out2[1]) and torch.equal(out[0], out2[0]) and torch.equal(out[2], out2[2]), guided
-        for (k, a), b in zip(sd_g.items(), tr2.gen.state_dict().values()):
+        for (k, a), b in zip(sd_g.items(), tr.gen.state_dict().values()):
             assert torch.equal(a, b.detach().cpu()), (guided, k)
-        for (k, a), b in zip(sd_d.items(), tr2.dis_a.state_dict().values()):
+        for (k, a), b in zip(sd_d.items(), tr.dis_a.state_dict().values()):
             assert torch.equal(a, b.detach().cpu()), (guided, k)
         if guided == 1:
             g_dis, g_gen, dis_p, kinks = out

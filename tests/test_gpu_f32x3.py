@@ -10,7 +10,9 @@ import torch
 from tests import test_gpu_ops as T
 from tests.parity import nerr
 
-pytestmark = pytest.mark.gpu
+# frozen_mode: an arithmetic mode no BASELINE.json config asks for (f32x3; bf16 MFMA operands on fp32 storage -- superseded by the
+# bf16-storage mode `bf16s`).  Frozen since round 3: kept working, no further work; `-m "gpu and not frozen_mode"` leaves them out.
+pytestmark = [pytest.mark.gpu, pytest.mark.frozen_mode]
 
 
 @pytest.fixture(autouse=True)

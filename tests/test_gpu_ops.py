@@ -117,28 +117,6 @@ def test_conv_stride2_winograd_on_small_shapes():
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
-def test_conv_winograd_f4x4_opt_in_path():
-    """MUNIT_WINOGRAD43=1 (read once per process by the library) routes the forward of the 3x3 / stride 1 layers and of the
-    sub-pixel phases whose extent is a multiple of 4 through Winograd F(4x4, 3x3) (conv_wino43.hip: -16 % time, ~10x the
-    rounding error of F(2x2, 3x3), hence opt-in).  A child process runs the convolution cases in that mode at the UNCHANGED
-    tolerances (2e-5 forward): partial 4x4-tile blocks (8x8, 20x24, 20x12), zero and reflect padding, fused activations, the
-    sub-pixel layers."""
-    import os, subprocess, sys
-    env = dict(os.environ, MUNIT_WINOGRAD43="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "test_conv_fwd_bwd and (k3s1 or k5s1)", "-p", "no:cacheprovider"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
-    # and the mode really is active in such a process
-    chk = ("import ctypes, torch\nfrom munit_amd import _lib, ops\nlib = _lib.load()\n"
-           "pl = ops._plan(2, 16, 16, 64, 64, 3, 3, 1, 1, 'reflect', False)\n"
-           "print(lib.munit_conv2d_kernel_name(pl.ref, 0).decode())")
-    r = subprocess.run([sys.executable, "-c", chk], env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "conv_wino43_kernel" in r.stdout, r.stdout + r.stderr
-
-
 def test_conv_wgrad_accumulates_into_buffer():
     """The trainer path: backward-weight adds into a preallocated buffer (beta = 1)."""
     from munit_amd import ops

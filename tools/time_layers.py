@@ -17,6 +17,11 @@ from munit_amd import ops  # noqa: E402
 SETS = {
     "s2": [(8, 256, 256, 64, 128, 4, 2, 1, False), (8, 128, 128, 128, 256, 4, 2, 1, False), (8, 64, 64, 256, 256, 4, 2, 1, False),
            (16, 128, 128, 64, 128, 4, 2, 1, False), (16, 64, 64, 128, 256, 4, 2, 1, False), (16, 32, 32, 256, 512, 4, 2, 1, False)],
+    # the smaller 4x4 / stride 2 layers: style encoder tail, discriminator scales 1 and 2 (fake + real batched: B = 16)
+    "s2small": [(8, 32, 32, 256, 256, 4, 2, 1, False), (8, 16, 16, 256, 256, 4, 2, 1, False),
+                (16, 64, 64, 64, 128, 4, 2, 1, False), (16, 32, 32, 128, 256, 4, 2, 1, False), (16, 16, 16, 256, 512, 4, 2, 1, False),
+                (16, 32, 32, 64, 128, 4, 2, 1, False), (16, 16, 16, 128, 256, 4, 2, 1, False), (16, 8, 8, 256, 512, 4, 2, 1, False),
+                (8, 128, 128, 64, 128, 4, 2, 1, False), (8, 64, 64, 128, 256, 4, 2, 1, False), (8, 32, 32, 256, 512, 4, 2, 1, False)],
     "up": [(8, 64, 64, 256, 128, 5, 1, 2, True), (8, 128, 128, 128, 64, 5, 1, 2, True)],
     "img": [(8, 256, 256, 3, 64, 7, 1, 3, False), (8, 256, 256, 64, 3, 7, 1, 3, False)],
     "trunk": [(8, 64, 64, 256, 256, 3, 1, 1, False)],

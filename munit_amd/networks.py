@@ -367,18 +367,23 @@ def _assign_adain_params(adain_params, model):
     if adain_params.dim() != 2:
         adain_params = adain_params.reshape(adain_params.size(0), -1)
     adain_params = adain_params.contiguous()
-    layers = [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"]
+    layers = model.__dict__.get("_munit_adain_layers")      # the walk over model.modules() costs ~0.1 ms: once per decoder
+    if layers is None:
+        layers = [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"]
+        model.__dict__["_munit_adain_layers"] = layers
     # When the layers' column ranges tile the tensor exactly (the shipped geometry: the MLP emits get_num_adain_params
     # columns), their backward passes write their slices of ONE gradient buffer and the first layer hands it to autograd
     # (ops.AdainGradSink) -- instead of eight zero-filled (B, n) tensors summed by seven element-wise kernels per decode.
     exact = sum(2 * m.num_features for m in layers) == adain_params.size(1)
     sink = ops.AdainGradSink() if (exact and torch.is_grad_enabled() and adain_params.requires_grad and ops.FUSE_ADAIN_GRAD) else None
     off = 0
+    det = adain_params.detach()
     for i, m in enumerate(layers):
         c = m.num_features
-        m._params = (adain_params, off + c, off, sink, i == 0)
-        m.bias = adain_params.detach()[:, off:off + c]
-        m.weight = adain_params.detach()[:, off + c:off + 2 * c]
+        d = m.__dict__                       # plain attributes (set to None in __init__): skip nn.Module.__setattr__'s type checks
+        d["_params"] = (adain_params, off + c, off, sink, i == 0)
+        d["bias"] = det[:, off:off + c]
+        d["weight"] = det[:, off + c:off + 2 * c]
         if adain_params.size(1) > off + 2 * c:
             off += 2 * c
 

@@ -13,11 +13,12 @@ def step():
     tr.update_learning_rate(); tr.dis_update(x_a, x_b, hp); tr.gen_update(x_a, x_b, hp, m_a, m_b)
 for _ in range(3): step()
 torch.cuda.synchronize()
-enq = []
-t0 = time.perf_counter()
-for _ in range(5):
+enq, t_all = [], 0.0
+for _ in range(6):
+    # every measured step starts on an idle device: once the host is several hundred launches ahead the runtime makes it wait for
+    # queue space, and a back-to-back loop then reads the DEVICE time per step instead of the host's
+    torch.cuda.synchronize()
     a = time.perf_counter(); step(); enq.append(time.perf_counter() - a)
-t_enq = time.perf_counter() - t0
-torch.cuda.synchronize()
-t_all = time.perf_counter() - t0
-print("host enqueue per step: %s ms ; wall per step incl. device: %.1f ms" % (" ".join("%.1f" % (1e3 * e) for e in enq), 1e3 * t_all / 5))
+    torch.cuda.synchronize()
+    t_all += time.perf_counter() - a
+print("host enqueue per step (each from an idle device): %s ms ; wall per step incl. device: %.1f ms" % (" ".join("%.1f" % (1e3 * e) for e in enq), 1e3 * t_all / 6))

@@ -17,7 +17,7 @@ extern "C" const char* munit_last_error(void) { return g_err; }
 // 2: munit_conv_desc carries in_dtype / out_dtype (a caller built against version 1 passes a short struct); the hipGraph
 // entry points of version 1 (munit_adam_step_graph, munit_store_floats, munit_stream_cross_wait) are gone.
 // 3: + munit_comm_unique_id / _init / _allreduce / _destroy, munit_shutdown (comm.hip); nothing removed or changed.
-extern "C" int munit_version(void) { return 3; }
+extern "C" int munit_version(void) { return 4; }
 
 // waiter stream waits for everything enqueued so far on signaler (both on the current device): hipEventRecord +
 // hipStreamWaitEvent on one cached event per (thread, device) -- the wait captures the event's state when it is issued, so

@@ -541,6 +541,9 @@ class MsImageDis(_ApplyRefreshesImages, nn.Module):
         self.cnns = nn.ModuleList()
         for _ in range(self.num_scales):
             self.cnns.append(self._make_net())
+        # called at the top of forward() -- calc_dis_loss / calc_gen_loss reach forward() directly, as the reference's do
+        # (networks.py:84-85, 104), so a module pre-hook would not see them
+        self.__dict__["before_forward"] = None
 
     def _make_net(self):
         dim = self.dim
@@ -557,6 +560,8 @@ class MsImageDis(_ApplyRefreshesImages, nn.Module):
         return ops.avgpool3s2(x)
 
     def forward(self, x):
+        if self.before_forward is not None:      # data parallel: order this stream behind a deferred optimizer step (trainer._wait_dis)
+            self.before_forward()
         x = ops.nhwc(x)
         outputs = []
         for i, model in enumerate(self.cnns):

@@ -479,7 +479,7 @@ class MUNIT_Trainer(_ApplyRefreshesImages, nn.Module):
         # deferred discriminator exchange + step (data parallel, _defer_dis_step)
         self._dis_pending, self._dis_event, self._dis_waited = None, None, set()
         for d in (self.dis_a, self.dis_b):
-            d.register_forward_pre_hook(self._wait_dis)
+            d.__dict__["before_forward"] = self._wait_dis     # every path into MsImageDis.forward, direct calls included
             d.register_state_dict_pre_hook(self._wait_dis)
         self._bind(torch.device("cpu"))
 
@@ -793,7 +793,7 @@ class MUNIT_Trainer(_ApplyRefreshesImages, nn.Module):
         that just ended on the caller's stream.  The caller's stream goes on: in the reference's iteration the next thing
         is gen_update (scripts/train.py:182-187), whose first ~15 ms -- two encodes, four decodes -- touch no discriminator
         weight, so the exchange runs beside them.  Whatever reads or writes the discriminators next waits for the recorded event
-        (`_wait_dis`: MsImageDis.forward through a pre-hook, dis_update, save / resume / state_dict)."""
+        (`_wait_dis`: the top of MsImageDis.forward, dis_update, save / resume / state_dict)."""
         import torch.distributed as dist
         comm = comm_stream(dev)
         ops.stream_wait(comm, torch.cuda.current_stream(dev))

@@ -87,7 +87,9 @@ def _worker(rank, world, tmpdir):
         stages = tr.last_exchange.stages
         assert len(stages) == 2 and all(st["fired"] for st in stages), stages
         assert stages[0]["ranges"] == [tuple(r) for r in tr._early_ranges] and stages[1]["ranges"] == [tuple(r) for r in tr._trunk_ranges]
-        assert tr._dis_pending is not None           # the discriminator step was deferred (and awaited by gen_update's D forward)
+        assert tr._dis_pending is not None           # the discriminator step was deferred ...
+        # ... and gen_update's discriminator forwards (calc_gen_loss -> forward, on the two branch streams) waited for it
+        assert len(tr._dis_waited) >= (2 if T.BRANCH_STREAMS else 1), tr._dis_waited
         sd_g = {k: v.detach().cpu().clone() for k, v in tr.gen.state_dict().items()}
         sd_d = {k: v.detach().cpu().clone() for k, v in tr.dis_a.state_dict().items()}
         # the same step with ONE all-reduce after backward and the discriminator step in line: bitwise the same averaged

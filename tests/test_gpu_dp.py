@@ -200,16 +200,21 @@ def run():
     torch.manual_seed(1234)
     tr = T.MUNIT_Trainer(hp); tr.to(dev)
     torch.manual_seed(11)
-    tr.update_learning_rate(); tr.dis_update(batch[0], batch[1], hp); tr.gen_update(batch[0], batch[1], hp, batch[2], batch[3])
+    for it in range(3):      # three iterations: the deferred discriminator step of one is settled by the next dis_update
+        tr.iterations = it
+        tr.update_learning_rate(); tr.dis_update(batch[0], batch[1], hp); tr.gen_update(batch[0], batch[1], hp, batch[2], batch[3])
     torch.cuda.synchronize()
     return tr
 
 ref = run()                                      # no process group yet: no exchange
 dist.init_process_group("nccl", init_method="file://" + %(rdzv)r, rank=0, world_size=1, device_id=dev)
 assert T.FORCE_ALLREDUCE
-got = run()                                      # same step with the RCCL all-reduce of both flat gradients issued
+got = run()                                      # same steps with the RCCL all-reduce of both flat gradients issued: staged
+# generator exchange, discriminator exchange + Adam on the communication stream beside the next generator forward
+assert got.last_exchange is not None and len(got.last_exchange.stages) == 2 and got._dis_pending is not None
 for a, b in zip(ref.parameters(), got.parameters()):
     assert torch.equal(a, b)
+assert torch.equal(ref.dis_opt.flat_m, got.dis_opt.flat_m) and torch.equal(ref.gen_opt.flat_v, got.gen_opt.flat_v)
 # and the exchange on its own: 109 MB flat generator gradient, device events on the stream RCCL is enqueued from
 g = got.gen_opt.flat_g
 before = g.clone()

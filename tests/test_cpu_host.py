@@ -530,6 +530,34 @@ def test_trainer_method_surface_is_the_reference_s():
     assert sig["comet_exp"].default is None and sig["synth"].default is False and sig["semantic_gt_a"].default is None
 
 
+def test_data_parallel_host_hooks_without_a_device():
+    """Host wiring of the data-parallel schedule on a CPU-built trainer (no kernel runs): the discriminators call the
+    trainer's wait at the top of forward() -- calc_gen_loss / calc_dis_loss reach forward() directly, as the reference's do
+    (networks.py:84-85, 104), so a module pre-hook would miss them --, the wait and the settle are no-ops while nothing is
+    pending, apply() on the trainer or on a sub-network works before any device buffer exists, the content encoders hand out the
+    tensor that enters their residual trunk only when asked, and the optimizer-step deferral is not taken without a process group."""
+    from munit_amd import trainer as T
+    from munit_amd.utils import weights_init
+    tr = T.MUNIT_Trainer(O.default_hp(64, 1, 1))
+    for d in (tr.dis_a, tr.dis_b):
+        assert d.before_forward == tr._wait_dis
+    assert tr._dis_pending is None and tr._wait_dis() is None
+    tr._settle_dis()
+    assert tr._dis_waited == set() and tr.last_exchange is None
+    w0 = tr.dis_a.cnns[0][0].conv.weight.detach().clone()
+    torch.manual_seed(5)
+    tr.dis_a.apply(weights_init("gaussian"))            # sub-network apply with the image refresh tail: no optimizer buffer on a device yet
+    tr.apply(weights_init("kaiming"))
+    assert not torch.equal(w0, tr.dis_a.cnns[0][0].conv.weight)
+    enc = tr._content_enc(1)
+    assert enc is tr.gen.enc1_content and tr._content_enc(2) is tr.gen.enc2_content
+    assert enc.keep_trunk_in is False and enc.trunk_in is None
+    assert T.dp_world() == 0                             # no process group: gen_update / dis_update take the in-line path
+    assert T.OVERLAP_EXCHANGE
+    # the state_dict of a discriminator goes through the wait as well (registered pre-hook) and is unchanged by it
+    assert list(tr.dis_a.state_dict().keys())[:2] == ["cnns.0.0.conv.weight", "cnns.0.0.conv.bias"]
+
+
 
 def test_bench_sizes_host_threads_from_the_granted_cpus(monkeypatch):
     """bench.py's thread pools (the ranks it launches, the CPU-baseline leg) are sized from the CPUs the process may use --
